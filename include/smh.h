@@ -1,0 +1,154 @@
+/* smh.h -- C ABI of libsmh.so: the MI355X (gfx950) implementation of the SM_HPSS_MTL hot path.
+ *
+ * The reference (mrinmoy-iitg/SM_HPSS_MTL) has NO C ABI of its own: its hot path is a Python call
+ * surface over librosa / scipy / sklearn / a Cython module / Keras.  Each entry point below therefore
+ * cites the reference Python call it replaces (paths under /root/reference).  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named `d_*` is DEVICE memory owned by the caller (e.g. torch tensors); the
+ *     library never allocates or frees caller buffers and keeps no global state besides the
+ *     immutable tables owned by an explicit `smh_ctx` / `smh_model`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
+ *     nothing synchronises, so every call is hipGraph-capturable;
+ *   - spectrogram-like tensors are (B, rows, T) row-major float32 -- per clip exactly the (K, T)
+ *     arrays librosa returns;
+ *   - return value: 0 = ok, <0 = error (SMH_E_*); smh_last_error() gives a thread-local message.
+ *   - no CPU fallback exists: without a HIP device every compute entry point fails with SMH_E_HIP.
+ */
+#ifndef SMH_H
+#define SMH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMH_OK 0
+#define SMH_E_INVALID (-1)   /* bad argument / unsupported size            */
+#define SMH_E_HIP (-2)       /* HIP runtime error (launch, alloc, no GPU)  */
+#define SMH_E_WORKSPACE (-3) /* caller workspace too small                 */
+
+#define SMH_MAX_MEDIAN 63 /* largest supported (odd) median window        */
+
+typedef struct smh_ctx smh_ctx;     /* front-end constant tables (window, twiddles, mel CSR)   */
+typedef struct smh_model smh_model; /* B3_MTL descriptor + packed device weights              */
+
+/* PARAMS keys the front end reads (Proposed_Work_Results.py:726-728,758-773,800-801). */
+typedef struct smh_frontend_cfg {
+    int32_t n_fft;      /* PARAMS['n_fft'][Model]: 400 (Jang: 512)                          */
+    int32_t win_length; /* int(Tw*fs/1000): 400                                             */
+    int32_t hop;        /* int(Ts*fs/1000): 160                                             */
+    int32_t n_mels;     /* PARAMS['n_mels'][Model]: 120; <=0 -> no mel projection (rows=K)  */
+    int32_t l_harm;     /* PARAMS['l_harm'][Model]: 21 (median along frames)                */
+    int32_t l_perc;     /* PARAMS['l_perc'][Model]: 11 (median along bins)                  */
+    int32_t log_db;     /* 1 -> librosa.power_to_db(x**2) ('Log*' feature names)            */
+    float mel_sr;       /* librosa default 22050 (the reference never passes sr)            */
+} smh_frontend_cfg;
+
+const char *smh_last_error(void);
+int smh_version(void);
+int smh_device_count(void); /* 0 when no HIP device is visible */
+
+int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out);
+void smh_ctx_destroy(smh_ctx *ctx);
+/* rows of one half (harmonic or percussive) of the featuregram: n_mels, or K = 1+n_fft/2 */
+int smh_ctx_feat_rows(const smh_ctx *ctx);
+/* copies the (n_mels, K) float32 mel basis to HOST memory (for inspection / tests) */
+int smh_ctx_mel_basis(const smh_ctx *ctx, float *h_out);
+
+/* ---- integer contracts (host, exact) ------------------------------------------------------- */
+/* librosa util.frame, center=False: 1 + (N - n_fft)/hop, 0 if N < n_fft */
+int smh_num_frames(int n_samples, int n_fft, int hop);
+/* get_feature_patches tiling (lib/preprocessing.py:139-142): frames after `while T<=W: append` */
+int smh_tiled_frames(int T, int W);
+/* tools.extract_patches (lib/cython_impl/tools.pyx:24-29): len(range(W/2, T-W/2, shift)) */
+int smh_num_patches(int T, int W, int shift);
+/* start frame of patch p (tools.pyx:30-34) */
+int smh_patch_start(int T, int W, int shift, int p);
+
+/* ---- a1: np.abs(librosa.core.stft(y, n_fft, win_length, hop_length, center=False)) ----------
+ * lib/preprocessing.py:407,417,429,439.  d_audio (B, n_samples) -> d_S (B, K, T).               */
+int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, float *d_S, void *stream);
+
+/* ---- a2: the two median filters inside librosa.decompose.hpss (preprocessing.py:408,418,...) --
+ * harm = median_filter(S, (1,l_harm), 'reflect');  perc = median_filter(S, (l_perc,1), 'reflect').
+ * Bit-exact selection.  smh_hpss_median_f32 computes both in ONE launch ("the median kernel").   */
+int smh_hpss_median_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_harm, int l_perc,
+                        float *d_harm, float *d_perc, void *stream);
+int smh_median_time_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_harm, float *d_harm,
+                        void *stream);
+int smh_median_freq_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_perc, float *d_perc,
+                        void *stream);
+
+/* ---- a3: H = S*softmask(harm,perc), P = S*softmask(perc,harm); power=2, split_zeros=True ---- */
+int smh_softmask_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, size_t n,
+                     float *d_H, float *d_P, void *stream);
+
+/* ---- a4: librosa.feature.melspectrogram(S=X, n_mels=) = mel_basis(22050, n_fft) @ X ---------
+ * d_X (B, K, T) -> d_Y (B, n_mels, T)  (preprocessing.py:409-410,419,421)                       */
+int smh_mel_f32(const smh_ctx *ctx, const float *d_X, int B, int T, float *d_Y, void *stream);
+
+/* ---- a5: librosa.core.power_to_db(X**2): 10*log10(max(1e-10, x^2)), then max(., max-80) with the
+ * max taken over each of the `n_arrays` arrays of `elems` values (preprocessing.py:420,422)      */
+int smh_power_to_db_sq_f32(const smh_ctx *ctx, const float *d_X, int n_arrays, int elems, float *d_Y, void *stream);
+
+/* ---- a7(iii): StandardScaler per row over frames (preprocessing.py:211-214,221-224) ----------
+ * d_X (n_rows, T) -> d_Y (n_rows, T): (x-mean)/std, population std, std==0 -> 1                  */
+int smh_standardize_rows_f32(const smh_ctx *ctx, const float *d_X, int n_rows, int T, float *d_Y, void *stream);
+
+/* ---- a8: tools.extract_patches incl. the tile-if-short rule of get_feature_patches -----------
+ * d_FV (B, F, T) -> patches.  layout 0: (B*nP, F, W) as the reference returns; layout 1:
+ * (B*nP, W, F) time-major = the TCN input after np.transpose (Proposed_Work_Results.py:235-236).
+ * Frames are taken modulo T when T < W (the tiled featuregram).  Returns nP per clip (>=0).     */
+int smh_extract_patches_f32(const smh_ctx *ctx, const float *d_FV, int B, int F, int T, int W, int shift, int layout,
+                            float *d_out, void *stream);
+
+/* ---- a3..a9 in two launches: (S, harm, perc) -> featuregram -> standardised time-major patches ------
+ * soft masks + mel + power_to_db (preprocessing.py:418-424) then tile / StandardScaler / patches /
+ * transpose (preprocessing.py:137-142,208-234; Proposed_Work_Results.py:235-236).
+ * d_fv (B, 2*rows, T) out; d_patches (B*nP, W, 2*rows) out or NULL; d_maxkeys: 2*B int32 scratch.
+ * Returns nP per clip.                                                                            */
+int smh_features_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int B, int T,
+                     int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys, void *stream);
+
+/* ---- fused fast path: get_featuregram (from Xin) + get_feature_patches for a batch of clips ---
+ * d_audio (B, n_samples) -> d_fv (B, 2*rows, T)  [the featuregram, = get_featuregram's return]
+ *                        -> d_patches (B*nP, W, 2*rows) time-major, standardised  [may be NULL]
+ * d_work: smh_frontend_workspace_bytes() bytes of scratch.  Optional parity taps (may be NULL):
+ * d_S, d_harm, d_perc (B, K, T).  Returns nP per clip.                                          */
+size_t smh_frontend_workspace_bytes(const smh_ctx *ctx, int B, int n_samples);
+int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, int W, int shift, float *d_fv,
+                     float *d_patches, void *d_work, size_t work_bytes, float *d_S, float *d_harm, float *d_perc,
+                     void *stream);
+
+/* ---- a10-a12: B3_MTL = get_Lemaire_MTL_model (lib/proposed_architectures.py:85-170, 25-80) ---- */
+typedef struct smh_model_cfg {
+    int32_t n_feat;     /* N_MELS argument = input_shape[1]: 240                       */
+    int32_t patch_size; /* W: 68 / 99 / 249                                            */
+    int32_t n_classes;  /* 3 (heads S,M,R[2],3C) or 5 (heads S,M,N,R[3],3C)            */
+    int32_t nb_filters; /* 32                                                          */
+    int32_t kernel_size;/* 3                                                           */
+    int32_t nb_stacks;  /* 3                                                           */
+    int32_t n_dilations;/* 8 -> dilations 1,2,...,128                                  */
+} smh_model_cfg;
+
+int smh_model_create(const smh_model_cfg *cfg, smh_model **out);
+void smh_model_destroy(smh_model *m);
+/* number of float32 parameters in canonical (Keras-layout) order, see DESIGN.md "weight order" */
+size_t smh_model_num_params(const smh_model *m);
+/* upload weights given as ONE flat host float32 array in canonical order */
+int smh_model_set_weights(smh_model *m, const float *h_flat, size_t n, void *stream);
+/* total width of the concatenated head outputs per patch: 3-class: 1+1+2+3 = 7; 5-class: 11 */
+int smh_model_out_dim(const smh_model *m);
+/* inference forward.  d_x (N, W, n_feat) float32 time-major -> d_out (N, out_dim) float32 holding
+ * [S | M | (N) | R | 3C-softmax] per row, i.e. model.predict's list concatenated on axis 1
+ * (Proposed_Work_Results.py:520,586).  d_trunk (N, W, nb_filters) optional TCN output tap.      */
+int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMH_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libsmh.so (C ABI: include/smh.h).  No CPU fallback: a missing library or a missing
+GPU is an error, never a silent detour."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmh.so")
+
+SMH_OK, SMH_E_INVALID, SMH_E_HIP, SMH_E_WORKSPACE = 0, -1, -2, -3
+
+
+class FrontendCfg(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("win_length", C.c_int32), ("hop", C.c_int32), ("n_mels", C.c_int32),
+                ("l_harm", C.c_int32), ("l_perc", C.c_int32), ("log_db", C.c_int32), ("mel_sr", C.c_float)]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("n_feat", C.c_int32), ("patch_size", C.c_int32), ("n_classes", C.c_int32),
+                ("nb_filters", C.c_int32), ("kernel_size", C.c_int32), ("nb_stacks", C.c_int32),
+                ("n_dilations", C.c_int32)]
+
+
+_vp, _i, _sz, _fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p  # device pointers travel as void*
+
+# name -> (restype, argtypes): exactly the declarations of include/smh.h
+SIGNATURES = {
+    "smh_last_error": (C.c_char_p, []),
+    "smh_version": (_i, []),
+    "smh_device_count": (_i, []),
+    "smh_ctx_create": (_i, [C.POINTER(FrontendCfg), C.POINTER(_vp)]),
+    "smh_ctx_destroy": (None, [_vp]),
+    "smh_ctx_feat_rows": (_i, [_vp]),
+    "smh_ctx_mel_basis": (_i, [_vp, _vp]),
+    "smh_num_frames": (_i, [_i, _i, _i]),
+    "smh_tiled_frames": (_i, [_i, _i]),
+    "smh_num_patches": (_i, [_i, _i, _i]),
+    "smh_patch_start": (_i, [_i, _i, _i, _i]),
+    "smh_stft_mag_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
+    "smh_hpss_median_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
+    "smh_median_time_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
+    "smh_median_freq_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
+    "smh_softmask_f32": (_i, [_vp, _fp, _fp, _fp, _sz, _fp, _fp, _vp]),
+    "smh_mel_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
+    "smh_power_to_db_sq_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
+    "smh_standardize_rows_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
+    "smh_extract_patches_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),
+    "smh_features_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
+    "smh_frontend_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "smh_frontend_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _fp, _fp, _fp, _vp]),
+    "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
+    "smh_model_destroy": (None, [_vp]),
+    "smh_model_num_params": (_sz, [_vp]),
+    "smh_model_set_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "smh_model_out_dim": (_i, [_vp]),
+    "smh_model_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsmh.so and type every entry point.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsmh.so not found at %s -- build it with `python -m sm_hpss_mtl_amd.build` "
+            "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().smh_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "libsmh") -> int:
+    """Map the C status to the Python exceptions the reference's callers would see
+    (numpy/librosa shape errors -> ValueError; runtime failures -> RuntimeError)."""
+    if rc >= 0:
+        return rc
+    msg = "%s: %s" % (what, last_error())
+    if rc == SMH_E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu():
+    lib = load()
+    if lib.smh_device_count() <= 0:
+        raise RuntimeError("no HIP device visible: the sm_hpss_mtl_amd compute path is GPU-only")
+    return lib

@@ -1,0 +1,60 @@
+// Internal helpers shared by the libsmh.so translation units (gfx950 only, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/smh.h"
+
+namespace smh {
+
+int set_error(int code, const char *fmt, ...);
+
+#define SMH_CHECK_HIP(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return smh::set_error(SMH_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                                  __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define SMH_REQUIRE(cond, ...)                                           \
+    do {                                                                 \
+        if (!(cond)) return smh::set_error(SMH_E_INVALID, __VA_ARGS__);  \
+    } while (0)
+
+inline int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(SMH_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return SMH_OK;
+}
+
+constexpr int kMaxFftStages = 12;
+constexpr int kLdsBytesPerCU = 160 * 1024;
+
+}  // namespace smh
+
+// Front-end context: immutable device tables + the config they were built for.
+struct smh_ctx {
+    smh_frontend_cfg cfg;
+    int K;         // bins = 1 + n_fft/2
+    int M;         // complex FFT length = n_fft/2 (real-input packing)
+    int n_stages;  // Stockham stages
+    int radix[smh::kMaxFftStages];
+    int feat_rows;  // rows of one half of the featuregram
+    // device tables
+    float *d_window;   // (n_fft) periodic Hann, centre-padded
+    float2 *d_twM;     // (M)   exp(-2 pi i j / M)
+    float2 *d_tw2M;    // (M+1) exp(-2 pi i k / (2M))
+    // mel filterbank, CSR by filter row
+    int n_mels;
+    int *d_mel_start;  // (n_mels) first bin with non-zero weight
+    int *d_mel_count;  // (n_mels) number of taps
+    int *d_mel_off;    // (n_mels) offset into d_mel_w
+    float *d_mel_w;    // (nnz)
+    int mel_nnz;
+    int mel_max_taps;
+    std::vector<float> h_mel_dense;  // (n_mels, K) host copy
+};

@@ -1,0 +1,22 @@
+// Internal interface between smh_feat.hip and smh_frontend.hip.
+#pragma once
+#include "smh_common.h"
+
+namespace smh_feat {
+
+struct MelTable {
+    int n_mels;
+    const int *start, *count, *off;
+    const float *w;
+};
+
+MelTable mel_table(const smh_ctx *c);
+
+// (S, harm, perc) -> featuregram fv (B, 2*rows, T) with un-clipped dB values + per-array max keys
+int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int B, int T, float *fv,
+                   int *maxkeys, float *H, float *P, hipStream_t st);
+// top_db clip (in place) + StandardScaler + time-major patches
+int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
+                     float *patches, hipStream_t st);
+
+}  // namespace smh_feat

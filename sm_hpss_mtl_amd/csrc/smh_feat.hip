@@ -1,0 +1,391 @@
+// a3-a8: soft masks, mel projection, power_to_db, per-row standardisation, patch extraction.
+// Stand-alone entry points mirror the reference's individual calls (parity API); the two fused kernels
+// at the bottom (hp_feat_kernel, std_patch_kernel) are what smh_frontend_f32 runs.
+#include <cfloat>
+
+#include "smh_common.h"
+#include "smh_feat.h"
+
+namespace {
+
+constexpr float kAmin = 1e-10f;   // librosa.power_to_db amin
+constexpr float kTopDb = 80.0f;   // librosa.power_to_db top_db
+
+// librosa.util.softmask(X, X_ref, power=2, split_zeros=True) for both orientations at once
+// (called from librosa.decompose.hpss with margin 1; lib/preprocessing.py:408,418,430,440).
+// Same float32 operation order as numpy: Z=max; bad=Z<tiny -> Z=1; (X/Z)^2; m/(m+r); bad -> 0.5.
+__device__ __forceinline__ void hpss_masks(float s, float h, float p, float &H, float &P) {
+    float Z = fmaxf(h, p);
+    const bool bad = Z < FLT_MIN;
+    Z = bad ? 1.0f : Z;
+    const float a = h / Z, b = p / Z;
+    const float m = __fmul_rn(a, a), r = __fmul_rn(b, b);  // no FMA contraction: numpy rounds the squares
+    const float den = __fadd_rn(m, r);
+    float mh = m / den, mp = r / den;
+    mh = bad ? 0.5f : mh;
+    mp = bad ? 0.5f : mp;
+    H = __fmul_rn(s, mh);
+    P = __fmul_rn(s, mp);
+}
+
+__global__ void softmask_kernel(const float *__restrict__ S, const float *__restrict__ harm,
+                                const float *__restrict__ perc, size_t n, float *__restrict__ H,
+                                float *__restrict__ P) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float hv, pv;
+        hpss_masks(S[i], harm[i], perc[i], hv, pv);
+        H[i] = hv;
+        P[i] = pv;
+    }
+}
+
+// librosa.feature.melspectrogram(S=X): mel_basis @ X with the sparse (CSR-by-row) filterbank.
+__global__ void mel_kernel(smh_feat::MelTable mel, const float *__restrict__ X, int K, int T, float *__restrict__ Y) {
+    const int b = blockIdx.y;
+    const int n = mel.n_mels * T;
+    const float *Xb = X + (size_t)b * K * T;
+    float *Yb = Y + (size_t)b * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int m = i / T, t = i - m * T;
+        const int k0 = mel.start[m], cnt = mel.count[m];
+        const float *w = mel.w + mel.off[m];
+        float acc = 0.f;
+        for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], Xb[(size_t)(k0 + j) * T + t], acc);
+        Yb[i] = acc;
+    }
+}
+
+__device__ __forceinline__ float db_of_sq(float x) {
+    const float p = __fmul_rn(x, x);
+    return 10.0f * log10f(fmaxf(kAmin, p));
+}
+
+template <typename Tv>
+__device__ __forceinline__ Tv block_reduce_max(Tv v, Tv *scratch) {
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    Tv r = scratch[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = max(r, scratch[w]);
+    return r;
+}
+
+// librosa.core.power_to_db(X**2): one workgroup per array (the top_db reference max is per array).
+__global__ void power_to_db_kernel(const float *__restrict__ X, int elems, float *__restrict__ Y) {
+    __shared__ float scratch[16];
+    const float *x = X + (size_t)blockIdx.x * elems;
+    float *y = Y + (size_t)blockIdx.x * elems;
+    float lmax = -FLT_MAX;
+    for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+        const float d = db_of_sq(x[i]);
+        y[i] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    const float thr = block_reduce_max(lmax, scratch) - kTopDb;
+    // each thread revisits exactly the elements it wrote itself
+    for (int i = threadIdx.x; i < elems; i += blockDim.x) y[i] = fmaxf(y[i], thr);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// sklearn StandardScaler statistics of one row held by one wave: float64 mean / population variance,
+// (near-)constant rows are left unscaled (sklearn _is_constant_feature / _handle_zeros_in_scale).
+template <typename Load>
+__device__ __forceinline__ void row_stats(int T, int lane, Load &&load, double &mean, double &scale) {
+    double s = 0.0;
+    for (int t = lane; t < T; t += 64) s += (double)load(t);
+    mean = wave_sum(s) / (double)T;
+    double q = 0.0;
+    for (int t = lane; t < T; t += 64) {
+        const double d = (double)load(t) - mean;
+        q += d * d;
+    }
+    const double var = wave_sum(q) / (double)T;
+    const double eps = 2.220446049250313e-16;
+    const double nm = (double)T * mean * eps;
+    const bool constant = var <= (double)T * eps * var + nm * nm;
+    scale = sqrt(var);
+    if (constant || scale == 0.0) scale = 1.0;
+}
+
+// `X -= mean; X /= scale` applied to a float32 array with float64 statistics: two roundings.
+__device__ __forceinline__ float standardize(float x, double mean, double scale) {
+    const float c = (float)((double)x - mean);
+    return (float)((double)c / scale);
+}
+
+__global__ void standardize_rows_kernel(const float *__restrict__ X, int n_rows, int T, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float *x = X + (size_t)row * T;
+    float *y = Y + (size_t)row * T;
+    double mean, scale;
+    row_stats(T, lane, [&](int t) { return x[t]; }, mean, scale);
+    for (int t = lane; t < T; t += 64) y[t] = standardize(x[t], mean, scale);
+}
+
+// tools.extract_patches on the (virtually) tiled featuregram: frame index taken modulo T.
+__global__ void extract_patches_kernel(const float *__restrict__ FV, int F, int T, int Ttiled, int W, int shift, int nP,
+                                       int layout, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t per_clip = (size_t)nP * F * W;
+    const float *fv = FV + (size_t)b * F * T;
+    float *o = out + (size_t)b * per_clip;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += (size_t)gridDim.x * blockDim.x) {
+        int p, f, j;
+        if (layout == 0) {  // (nP, F, W)
+            j = (int)(i % W);
+            f = (int)((i / W) % F);
+            p = (int)(i / ((size_t)W * F));
+        } else {  // (nP, W, F)
+            f = (int)(i % F);
+            j = (int)((i / F) % W);
+            p = (int)(i / ((size_t)W * F));
+        }
+        const int half = W / 2;
+        int s = p * shift;  // centre half + p*shift, start = centre - half
+        const int e = min(s + W, Ttiled);
+        if (e - s < W) s = e - W;
+        (void)half;
+        o[i] = fv[(size_t)f * T + (s + j) % T];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused fast path, kernel 1: (S, harm, perc) slab -> soft masks -> H,P in LDS -> mel -> dB (unclipped)
+// grid (time slabs, B).  The per-array top_db maximum is accumulated with one atomicMax per workgroup
+// and applied by std_patch_kernel, which owns whole featuregram halves.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ordered_key(float f) {
+    const int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float key_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+__global__ void __launch_bounds__(256)
+hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, const float *__restrict__ harm,
+               const float *__restrict__ perc, int K, int T, int TS, int rows, float *__restrict__ fv,
+               int *__restrict__ maxkeys, float *__restrict__ Hout, float *__restrict__ Pout) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int smax[2 * 4];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TS;
+    const int nt = min(TS, T - t0);
+    const int ld = TS | 1;
+    float *Hs = lds, *Ps = lds + (size_t)K * ld;
+    const size_t cb = (size_t)b * K * T;
+    for (int i = threadIdx.x; i < K * nt; i += blockDim.x) {
+        const int k = i / nt, c = i - k * nt;
+        const size_t g = cb + (size_t)k * T + t0 + c;
+        float hv, pv;
+        hpss_masks(S[g], harm[g], perc[g], hv, pv);
+        Hs[k * ld + c] = hv;
+        Ps[k * ld + c] = pv;
+        if (Hout) Hout[g] = hv;
+        if (Pout) Pout[g] = pv;
+    }
+    __syncthreads();
+    float mxH = -FLT_MAX, mxP = -FLT_MAX;
+    float *fvH = fv + (size_t)b * 2 * rows * T + t0;
+    float *fvP = fvH + (size_t)rows * T;
+    for (int i = threadIdx.x; i < rows * nt; i += blockDim.x) {
+        const int m = i / nt, c = i - m * nt;
+        float aH, aP;
+        if (mel.n_mels > 0) {
+            const int k0 = mel.start[m], cnt = mel.count[m];
+            const float *w = mel.w + mel.off[m];
+            aH = 0.f, aP = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                aH = fmaf(w[j], Hs[(k0 + j) * ld + c], aH);
+                aP = fmaf(w[j], Ps[(k0 + j) * ld + c], aP);
+            }
+        } else {
+            aH = Hs[m * ld + c];
+            aP = Ps[m * ld + c];
+        }
+        if (log_db) {
+            aH = db_of_sq(aH);
+            aP = db_of_sq(aP);
+            mxH = fmaxf(mxH, aH);
+            mxP = fmaxf(mxP, aP);
+        }
+        fvH[(size_t)m * T + c] = aH;
+        fvP[(size_t)m * T + c] = aP;
+    }
+    if (log_db) {
+        int kH = ordered_key(mxH), kP = ordered_key(mxP);
+        for (int off = 32; off > 0; off >>= 1) {
+            kH = max(kH, __shfl_xor(kH, off));
+            kP = max(kP, __shfl_xor(kP, off));
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) smax[wave] = kH, smax[4 + wave] = kP;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMax(&maxkeys[2 * b], max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+            atomicMax(&maxkeys[2 * b + 1], max(max(smax[4], smax[5]), max(smax[6], smax[7])));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused fast path, kernel 2: one workgroup per (clip, half): top_db clip (written back: the final
+// featuregram) -> StandardScaler per row -> time-major patches (B*nP, W, 2*rows) for the TCN.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ maxkeys, int rows, int T, int Ttiled, int W,
+                 int shift, int nP, float *__restrict__ patches) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int b = blockIdx.y, half = blockIdx.x;
+    const int ld = T | 1;
+    float *g = fv + ((size_t)b * 2 + half) * rows * T;
+    const float thr = log_db ? key_to_float(maxkeys[2 * b + half]) - kTopDb : -FLT_MAX;
+    for (int i = threadIdx.x; i < rows * T; i += blockDim.x) {
+        const int r = i / T, t = i - r * T;
+        float v = g[i];
+        if (log_db) {
+            v = fmaxf(v, thr);
+            g[i] = v;
+        }
+        tile[r * ld + t] = v;
+    }
+    __syncthreads();
+    if (!patches) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        float *row = tile + r * ld;
+        double mean, scale;
+        row_stats(T, lane, [&](int t) { return row[t]; }, mean, scale);
+        for (int t = lane; t < T; t += 64) row[t] = standardize(row[t], mean, scale);
+    }
+    __syncthreads();
+    const int F = 2 * rows;
+    for (int p = 0; p < nP; ++p) {
+        int s = p * shift;
+        const int e = min(s + W, Ttiled);
+        if (e - s < W) s = e - W;
+        float *o = patches + ((size_t)b * nP + p) * W * F + (size_t)half * rows;
+        for (int i = threadIdx.x; i < W * rows; i += blockDim.x) {
+            const int j = i / rows, f = i - j * rows;
+            o[(size_t)j * F + f] = tile[f * ld + (s + j) % T];
+        }
+    }
+}
+
+__global__ void fill_int_kernel(int *p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+namespace smh_feat {
+
+MelTable mel_table(const smh_ctx *c) {
+    MelTable m;
+    m.n_mels = c->n_mels;
+    m.start = c->d_mel_start, m.count = c->d_mel_count, m.off = c->d_mel_off, m.w = c->d_mel_w;
+    return m;
+}
+
+int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int B, int T, float *fv,
+                   int *maxkeys, float *H, float *P, hipStream_t st) {
+    const int K = c->K, rows = c->feat_rows;
+    // slab width: keep 2*K*(TS|1) floats under 64 KiB
+    int TS = (64 * 1024 / 4) / (2 * K);
+    if (TS > 32) TS = 32;
+    if ((TS & 1) == 0) TS -= 1;
+    if (TS < 1) return smh::set_error(SMH_E_INVALID, "K=%d too large for the feature kernel", K);
+    if (TS > T) TS = T;
+    const size_t lds = sizeof(float) * 2 * (size_t)K * (TS | 1);
+    if (c->cfg.log_db) {
+        hipLaunchKernelGGL(fill_int_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, maxkeys, 2 * B, (int)0x80000000);
+        int rc = smh::launch_status("fill_int_kernel");
+        if (rc) return rc;
+    }
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hp_feat_kernel, dim3((T + TS - 1) / TS, B), dim3(256), lds, st, mel_table(c), c->cfg.log_db, S, harm,
+                       perc, K, T, TS, rows, fv, maxkeys, H, P);
+    return smh::launch_status("hp_feat_kernel");
+}
+
+int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
+                     float *patches, hipStream_t st) {
+    const int rows = c->feat_rows;
+    const size_t lds = sizeof(float) * (size_t)rows * (T | 1);
+    if (lds > 150 * 1024)
+        return smh::set_error(SMH_E_INVALID, "clip of %d frames x %d rows exceeds the LDS tile of the patch kernel", T, rows);
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(std_patch_kernel, dim3(2, B), dim3(256), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
+                       smh_tiled_frames(T, W), W, shift, nP, patches);
+    return smh::launch_status("std_patch_kernel");
+}
+
+}  // namespace smh_feat
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int smh_softmask_f32(const smh_ctx *, const float *d_S, const float *d_harm, const float *d_perc, size_t n,
+                                float *d_H, float *d_P, void *stream) {
+    SMH_REQUIRE(d_S && d_harm && d_perc && d_H && d_P, "smh_softmask_f32: null argument");
+    if (n == 0) return SMH_OK;
+    const int bs = 256;
+    size_t nb = (n + bs - 1) / bs;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(softmask_kernel, dim3((unsigned)nb), dim3(bs), 0, (hipStream_t)stream, d_S, d_harm, d_perc, n, d_H,
+                       d_P);
+    return smh::launch_status("softmask_kernel");
+}
+
+extern "C" int smh_mel_f32(const smh_ctx *ctx, const float *d_X, int B, int T, float *d_Y, void *stream) {
+    SMH_REQUIRE(ctx && d_X && d_Y, "smh_mel_f32: null argument");
+    SMH_REQUIRE(ctx->n_mels > 0, "smh_mel_f32: context built without a mel filterbank (n_mels <= 0)");
+    SMH_REQUIRE(B >= 0 && B <= 65535 && T >= 1, "smh_mel_f32: bad shape B=%d T=%d", B, T);
+    if (B == 0) return SMH_OK;
+    const int n = ctx->n_mels * T;
+    hipLaunchKernelGGL(mel_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, smh_feat::mel_table(ctx),
+                       d_X, ctx->K, T, d_Y);
+    return smh::launch_status("mel_kernel");
+}
+
+extern "C" int smh_power_to_db_sq_f32(const smh_ctx *, const float *d_X, int n_arrays, int elems, float *d_Y,
+                                      void *stream) {
+    SMH_REQUIRE(d_X && d_Y, "smh_power_to_db_sq_f32: null argument");
+    SMH_REQUIRE(n_arrays >= 0 && elems >= 1, "smh_power_to_db_sq_f32: bad shape");
+    if (n_arrays == 0) return SMH_OK;
+    hipLaunchKernelGGL(power_to_db_kernel, dim3(n_arrays), dim3(256), 0, (hipStream_t)stream, d_X, elems, d_Y);
+    return smh::launch_status("power_to_db_kernel");
+}
+
+extern "C" int smh_standardize_rows_f32(const smh_ctx *, const float *d_X, int n_rows, int T, float *d_Y, void *stream) {
+    SMH_REQUIRE(d_X && d_Y, "smh_standardize_rows_f32: null argument");
+    SMH_REQUIRE(n_rows >= 0 && T >= 1, "smh_standardize_rows_f32: bad shape");
+    if (n_rows == 0) return SMH_OK;
+    hipLaunchKernelGGL(standardize_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_X, n_rows, T,
+                       d_Y);
+    return smh::launch_status("standardize_rows_kernel");
+}
+
+extern "C" int smh_extract_patches_f32(const smh_ctx *, const float *d_FV, int B, int F, int T, int W, int shift,
+                                       int layout, float *d_out, void *stream) {
+    SMH_REQUIRE(d_FV, "smh_extract_patches_f32: null input");
+    SMH_REQUIRE(B >= 0 && B <= 65535 && F >= 1 && T >= 1 && W >= 1 && shift >= 1, "smh_extract_patches_f32: bad shape");
+    SMH_REQUIRE(layout == 0 || layout == 1, "smh_extract_patches_f32: layout must be 0 or 1");
+    const int Ttiled = smh_tiled_frames(T, W);
+    const int nP = smh_num_patches(Ttiled, W, shift);
+    if (nP <= 0 || B == 0) return nP < 0 ? SMH_E_INVALID : nP;
+    SMH_REQUIRE(d_out, "smh_extract_patches_f32: null output");
+    const size_t per_clip = (size_t)nP * F * W;
+    size_t nb = (per_clip + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(extract_patches_kernel, dim3((unsigned)nb, B), dim3(256), 0, (hipStream_t)stream, d_FV, F, T, Ttiled,
+                       W, shift, nP, layout, d_out);
+    int rc = smh::launch_status("extract_patches_kernel");
+    return rc ? rc : nP;
+}

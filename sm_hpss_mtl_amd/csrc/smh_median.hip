@@ -1,0 +1,194 @@
+// Entry points of the HPSS median filters (kernel template: smh_median_kernel.h).
+#include "smh_median_kernel.h"
+
+namespace smh_median {
+
+const Entry kPairs[] = {
+    // both filters in ONE launch: the reference's configuration (21,11), BASELINE config 2 (17,17)
+    // and the reference's sweep {11,21,31,41,51}^2 (Hyperparameter_Selection.py:543-544)
+    SMH_MEDIAN_E2(21, 11) SMH_MEDIAN_E2(17, 17)
+    SMH_MEDIAN_E2(11, 11) SMH_MEDIAN_E2(11, 21) SMH_MEDIAN_E2(11, 31) SMH_MEDIAN_E2(11, 41) SMH_MEDIAN_E2(11, 51)
+    SMH_MEDIAN_E2(21, 21) SMH_MEDIAN_E2(21, 31) SMH_MEDIAN_E2(21, 41) SMH_MEDIAN_E2(21, 51)
+    SMH_MEDIAN_E2(31, 11) SMH_MEDIAN_E2(31, 21) SMH_MEDIAN_E2(31, 31) SMH_MEDIAN_E2(31, 41) SMH_MEDIAN_E2(31, 51)
+    SMH_MEDIAN_E2(41, 11) SMH_MEDIAN_E2(41, 21) SMH_MEDIAN_E2(41, 31) SMH_MEDIAN_E2(41, 41) SMH_MEDIAN_E2(41, 51)
+    SMH_MEDIAN_E2(51, 11) SMH_MEDIAN_E2(51, 21) SMH_MEDIAN_E2(51, 31) SMH_MEDIAN_E2(51, 41) SMH_MEDIAN_E2(51, 51)};
+
+KernelFn find_pair_kernel(int lh, int lp) {
+    for (const Entry &e : kPairs)
+        if (e.lh == lh && e.lp == lp) return e.fn;
+    return nullptr;
+}
+
+}  // namespace smh_median
+
+namespace {
+
+using namespace smh_median;
+
+// Slow, fully general path for axes not longer than half the window (multiple reflections):
+// one thread per output, rank-counting selection.  Only tiny inputs ever reach it.
+__global__ void median_small_kernel(const float *__restrict__ S, float *__restrict__ out, int K, int T, int w,
+                                    int along_t, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = (int)(i % T);
+    const int k = (int)((i / T) % K);
+    const size_t base = i - (size_t)k * T - t;
+    const int n = along_t ? T : K;
+    const int pos = along_t ? t : k;
+    const int h = w / 2;
+    auto at = [&](int j) {
+        int q = pos - h + j;
+        const int p = 2 * n;
+        int r = q % p;
+        if (r < 0) r += p;
+        if (r >= n) r = p - 1 - r;
+        return along_t ? S[base + (size_t)k * T + r] : S[base + (size_t)r * T + t];
+    };
+    // the median is the element with exactly h elements before it in the stable (value, index) order
+    for (int a = 0; a < w; ++a) {
+        const float va = at(a);
+        int rank = 0;
+        for (int c = 0; c < w; ++c) {
+            const float vc = at(c);
+            rank += (vc < va) || (vc == va && c < a);
+        }
+        if (rank == h) {
+            out[i] = va;
+            return;
+        }
+    }
+}
+
+struct Plan {
+    int TT, ntiles, stride, nsh, nsp, nwh, nwp;
+    size_t lds;
+};
+
+// Tile so that two workgroups fit one CU's 160 KiB LDS whenever the clip allows it.
+int make_plan(int K, int T, int lh, int lp, Plan *p) {
+    const int hh = lh / 2;
+    const int budget_words = (smh::kLdsBytesPerCU / 2 - 1024) / 4;
+    auto odd = [](int x) { return x | 1; };
+    int TT, stride;
+    if ((size_t)K * odd(T) <= (size_t)budget_words) {
+        TT = T;
+        stride = odd(T);
+    } else {
+        int maxcols = budget_words / K;
+        if ((maxcols & 1) == 0) maxcols -= 1;
+        TT = maxcols - 2 * hh;
+        if (TT < 8) {
+            // very tall spectrograms: give one workgroup the whole 160 KiB
+            maxcols = ((smh::kLdsBytesPerCU - 1024) / 4) / K;
+            if ((maxcols & 1) == 0) maxcols -= 1;
+            TT = maxcols - 2 * hh;
+            if (TT < 1) return smh::set_error(SMH_E_INVALID, "K=%d too large for an LDS tile with l_harm=%d", K, lh);
+        }
+        if (TT > T) TT = T;
+        stride = odd(TT + 2 * hh);
+    }
+    p->TT = TT;
+    p->ntiles = (T + TT - 1) / TT;
+    p->stride = stride;
+    p->lds = (size_t)K * stride * sizeof(float);
+    // segments: aim at similar lane-task lengths and <= 16 waves per workgroup
+    const int nt = TT;
+    int nsh = lh ? 2 : 0, nsp = lp ? 3 : 0;
+    if (lh && nt < 2 * lh) nsh = 1;
+    if (lp && K < 6 * lp) nsp = 1;
+    auto waves = [&](int n, int seg) { return seg ? (n * seg + 63) / 64 : 0; };
+    int nwh = waves(K, nsh), nwp = waves(nt, nsp);
+    while (nwh + nwp > 16) {
+        if (nsh > 1 && nwh >= nwp) nsh--;
+        else if (nsp > 1) nsp--;
+        else if (nsh > 1) nsh--;
+        else break;
+        nwh = waves(K, nsh), nwp = waves(nt, nsp);
+    }
+    if (nwh + nwp > 16)
+        return smh::set_error(SMH_E_INVALID, "tile %dx%d needs more than 16 waves per workgroup", K, nt);
+    p->nsh = nsh, p->nsp = nsp, p->nwh = nwh, p->nwp = nwp;
+    return SMH_OK;
+}
+
+int launch_small(const float *S, int B, int K, int T, int w, int along_t, float *out, hipStream_t st) {
+    const size_t total = (size_t)B * K * T;
+    const int bs = 256;
+    hipLaunchKernelGGL(median_small_kernel, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, S, out, K, T, w,
+                       along_t, total);
+    return smh::launch_status("median_small_kernel");
+}
+
+int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, hipStream_t st) {
+    KernelFn fn = (lh && lp) ? find_pair_kernel(lh, lp) : find_single_kernel(lh, lp);
+    if (!fn) return smh::set_error(SMH_E_INVALID, "no median kernel for (l_harm,l_perc)=(%d,%d)", lh, lp);
+    Plan p;
+    int rc = make_plan(K, T, lh, lp, &p);
+    if (rc) return rc;
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    dim3 grid(p.ntiles, B), block((p.nwh + p.nwp) * 64);
+    hipLaunchKernelGGL(fn, grid, block, p.lds, st, S, harm, perc, K, T, p.TT, p.stride, p.nsh, p.nsp, p.nwh,
+                       -__builtin_inff(), __builtin_inff());
+    return smh::launch_status("hpss_median_kernel");
+}
+
+int check_args(const void *S, int B, int K, int T, int w, const char *name) {
+    SMH_REQUIRE(S != nullptr, "%s: null input", name);
+    SMH_REQUIRE(B >= 0 && K >= 1 && T >= 1, "%s: bad shape B=%d K=%d T=%d", name, B, K, T);
+    SMH_REQUIRE(w >= 1 && w <= SMH_MAX_MEDIAN && (w & 1), "%s: window must be odd in [1,%d], got %d", name,
+                SMH_MAX_MEDIAN, w);
+    SMH_REQUIRE(B <= 65535, "%s: B=%d exceeds the grid limit; split the batch", name, B);
+    return SMH_OK;
+}
+
+// the register-window kernel folds once per side: it needs window/2 < axis length
+bool fast_ok(int n, int w) { return w >= 3 && w / 2 + 4 < n; }
+
+}  // namespace
+
+extern "C" int smh_median_time_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_harm, float *d_harm,
+                                   void *stream) {
+    int rc = check_args(d_S, B, K, T, l_harm, "smh_median_time_f32");
+    if (rc) return rc;
+    SMH_REQUIRE(d_harm, "smh_median_time_f32: null output");
+    if (B == 0) return SMH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (l_harm == 1) {
+        SMH_CHECK_HIP(hipMemcpyAsync(d_harm, d_S, (size_t)B * K * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return SMH_OK;
+    }
+    if (!fast_ok(T, l_harm)) return launch_small(d_S, B, K, T, l_harm, 1, d_harm, st);
+    return launch(d_S, B, K, T, l_harm, 0, d_harm, nullptr, st);
+}
+
+extern "C" int smh_median_freq_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_perc, float *d_perc,
+                                   void *stream) {
+    int rc = check_args(d_S, B, K, T, l_perc, "smh_median_freq_f32");
+    if (rc) return rc;
+    SMH_REQUIRE(d_perc, "smh_median_freq_f32: null output");
+    if (B == 0) return SMH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (l_perc == 1) {
+        SMH_CHECK_HIP(hipMemcpyAsync(d_perc, d_S, (size_t)B * K * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return SMH_OK;
+    }
+    if (!fast_ok(K, l_perc)) return launch_small(d_S, B, K, T, l_perc, 0, d_perc, st);
+    return launch(d_S, B, K, T, 0, l_perc, nullptr, d_perc, st);
+}
+
+extern "C" int smh_hpss_median_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_harm, int l_perc,
+                                   float *d_harm, float *d_perc, void *stream) {
+    int rc = check_args(d_S, B, K, T, l_harm, "smh_hpss_median_f32");
+    if (rc) return rc;
+    rc = check_args(d_S, B, K, T, l_perc, "smh_hpss_median_f32");
+    if (rc) return rc;
+    SMH_REQUIRE(d_harm && d_perc, "smh_hpss_median_f32: null output");
+    if (B == 0) return SMH_OK;
+    if (fast_ok(T, l_harm) && fast_ok(K, l_perc) && find_pair_kernel(l_harm, l_perc))
+        return launch(d_S, B, K, T, l_harm, l_perc, d_harm, d_perc, (hipStream_t)stream);
+    // window pairs outside the fused table, or tiny axes: one launch per filter
+    rc = smh_median_time_f32(nullptr, d_S, B, K, T, l_harm, d_harm, stream);
+    if (rc) return rc;
+    return smh_median_freq_f32(nullptr, d_S, B, K, T, l_perc, d_perc, stream);
+}

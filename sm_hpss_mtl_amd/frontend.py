@@ -1,0 +1,241 @@
+"""Device-resident batched front end: thin host wrapper over the C ABI (include/smh.h).
+
+torch is plumbing here (device memory + the current HIP stream); every computation happens in
+libsmh.so.  Inputs/outputs are float32 CUDA(=HIP) tensors, spectrogram-like tensors are (B, rows, T).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# featName -> (n_mels used?, log?)   (lib/preprocessing.py:404-444; only the '*HarmPerc*' branches are
+# on the hot path -- SURVEY 8a)
+FEATS = {
+    "MelHarmPercSpec": (True, False),
+    "LogMelHarmPercSpec": (True, True),
+    "HarmPercSpec": (False, False),
+    "LogHarmPercSpec": (False, True),
+}
+
+
+@dataclass(frozen=True)
+class FrontendConfig:
+    n_fft: int = 400
+    win_length: int = 400
+    hop: int = 160
+    n_mels: int = 120
+    l_harm: int = 21
+    l_perc: int = 11
+    log_db: bool = True
+    mel_sr: float = 22050.0
+
+    @staticmethod
+    def from_params(PARAMS, n_fft, n_mels, featName, fs=16000):
+        """Build from the reference's PARAMS dict (Proposed_Work_Results.py:723-807)."""
+        if featName not in FEATS:
+            raise ValueError("featName %r is not one of the HPSS feature names %s" % (featName, sorted(FEATS)))
+        use_mel, log = FEATS[featName]
+        model = PARAMS["Model"]
+        return FrontendConfig(
+            n_fft=int(n_fft), win_length=int(PARAMS["Tw"] * fs / 1000), hop=int(PARAMS["Ts"] * fs / 1000),
+            n_mels=int(n_mels) if use_mel else 0, l_harm=int(PARAMS["l_harm"][model]),
+            l_perc=int(PARAMS["l_perc"][model]), log_db=log)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP torch tensor" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+class Frontend:
+    """Owns one `smh_ctx` (window, FFT twiddles, mel CSR tables) for a fixed configuration."""
+
+    def __init__(self, cfg: FrontendConfig = FrontendConfig()):
+        self.lib = _lib.require_gpu()
+        self.cfg = cfg
+        c = _lib.FrontendCfg(cfg.n_fft, cfg.win_length, cfg.hop, cfg.n_mels, cfg.l_harm, cfg.l_perc,
+                             1 if cfg.log_db else 0, cfg.mel_sr)
+        h = C.c_void_p()
+        _lib.check(self.lib.smh_ctx_create(C.byref(c), C.byref(h)), "smh_ctx_create")
+        self._h = h
+        self.K = 1 + cfg.n_fft // 2
+        self.rows = self.lib.smh_ctx_feat_rows(self._h)
+        self._work = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.smh_ctx_destroy(h)
+            self._h = None
+
+    # ---- integer contracts ----
+    def num_frames(self, n_samples: int) -> int:
+        return self.lib.smh_num_frames(n_samples, self.cfg.n_fft, self.cfg.hop)
+
+    def num_patches(self, T: int, W: int, shift: int) -> int:
+        return _lib.check(self.lib.smh_num_patches(self.lib.smh_tiled_frames(T, W), W, shift), "smh_num_patches")
+
+    def mel_basis(self) -> np.ndarray:
+        out = np.empty((self.cfg.n_mels, self.K), np.float32)
+        _lib.check(self.lib.smh_ctx_mel_basis(self._h, out.ctypes.data_as(C.c_void_p)), "smh_ctx_mel_basis")
+        return out
+
+    # ---- stage-by-stage API (one call per reference call) ----
+    def stft_mag(self, audio):
+        audio = _f32c(audio, "audio")
+        B, N = audio.shape
+        T = self.num_frames(N)
+        if T < 1:
+            raise ValueError("clip of %d samples is shorter than n_fft=%d" % (N, self.cfg.n_fft))
+        S = torch.empty((B, self.K, T), dtype=torch.float32, device=audio.device)
+        _lib.check(self.lib.smh_stft_mag_f32(self._h, _ptr(audio), B, N, _ptr(S), _stream()), "smh_stft_mag_f32")
+        return S
+
+    def hpss_median(self, S, l_harm=None, l_perc=None):
+        S = _f32c(S, "S")
+        B, K, T = S.shape
+        lh = self.cfg.l_harm if l_harm is None else l_harm
+        lp = self.cfg.l_perc if l_perc is None else l_perc
+        harm, perc = torch.empty_like(S), torch.empty_like(S)
+        _lib.check(self.lib.smh_hpss_median_f32(self._h, _ptr(S), B, K, T, lh, lp, _ptr(harm), _ptr(perc), _stream()),
+                   "smh_hpss_median_f32")
+        return harm, perc
+
+    def median_time(self, S, l_harm):
+        S = _f32c(S, "S")
+        B, K, T = S.shape
+        out = torch.empty_like(S)
+        _lib.check(self.lib.smh_median_time_f32(self._h, _ptr(S), B, K, T, l_harm, _ptr(out), _stream()),
+                   "smh_median_time_f32")
+        return out
+
+    def median_freq(self, S, l_perc):
+        S = _f32c(S, "S")
+        B, K, T = S.shape
+        out = torch.empty_like(S)
+        _lib.check(self.lib.smh_median_freq_f32(self._h, _ptr(S), B, K, T, l_perc, _ptr(out), _stream()),
+                   "smh_median_freq_f32")
+        return out
+
+    def softmask(self, S, harm, perc):
+        S, harm, perc = _f32c(S, "S"), _f32c(harm, "harm"), _f32c(perc, "perc")
+        if not (S.shape == harm.shape == perc.shape):
+            raise ValueError("softmask: shape mismatch %s %s %s" % (S.shape, harm.shape, perc.shape))
+        H, P = torch.empty_like(S), torch.empty_like(S)
+        _lib.check(self.lib.smh_softmask_f32(self._h, _ptr(S), _ptr(harm), _ptr(perc), S.numel(), _ptr(H), _ptr(P),
+                                             _stream()), "smh_softmask_f32")
+        return H, P
+
+    def mel(self, X):
+        X = _f32c(X, "X")
+        B, K, T = X.shape
+        if K != self.K:
+            raise ValueError("mel: expected %d bins, got %d" % (self.K, K))
+        Y = torch.empty((B, self.cfg.n_mels, T), dtype=torch.float32, device=X.device)
+        _lib.check(self.lib.smh_mel_f32(self._h, _ptr(X), B, T, _ptr(Y), _stream()), "smh_mel_f32")
+        return Y
+
+    def power_to_db_sq(self, X):
+        """power_to_db(X**2) with the top_db max taken per leading-axis entry."""
+        X = _f32c(X, "X")
+        n = X.shape[0]
+        Y = torch.empty_like(X)
+        _lib.check(self.lib.smh_power_to_db_sq_f32(self._h, _ptr(X), n, X.numel() // max(n, 1), _ptr(Y), _stream()),
+                   "smh_power_to_db_sq_f32")
+        return Y
+
+    def standardize_rows(self, X):
+        X = _f32c(X, "X")
+        T = X.shape[-1]
+        Y = torch.empty_like(X)
+        _lib.check(self.lib.smh_standardize_rows_f32(self._h, _ptr(X), X.numel() // T, T, _ptr(Y), _stream()),
+                   "smh_standardize_rows_f32")
+        return Y
+
+    def extract_patches(self, FV, W, shift, time_major=False):
+        FV = _f32c(FV, "FV")
+        B, F, T = FV.shape
+        nP = self.num_patches(T, W, shift)
+        shape = (B * nP, W, F) if time_major else (B * nP, F, W)
+        out = torch.empty(shape, dtype=torch.float32, device=FV.device)
+        got = _lib.check(self.lib.smh_extract_patches_f32(self._h, _ptr(FV), B, F, T, W, shift, 1 if time_major else 0,
+                                                          _ptr(out) if nP else None, _stream()), "smh_extract_patches_f32")
+        assert got == nP
+        return out
+
+    def features(self, S, harm, perc, W=None, shift=None, out=None):
+        """(S, harm, perc) -> dict(fv[, patches]): masks + mel + dB, then standardise + time-major patches."""
+        S, harm, perc = _f32c(S, "S"), _f32c(harm, "harm"), _f32c(perc, "perc")
+        B, K, T = S.shape
+        out = {} if out is None else out
+        fv = out.get("fv")
+        if fv is None:
+            fv = torch.empty((B, 2 * self.rows, T), dtype=torch.float32, device=S.device)
+        nP, patches = 0, None
+        if W is not None:
+            nP = self.num_patches(T, W, shift)
+            patches = out.get("patches")
+            if patches is None:
+                patches = torch.empty((B * nP, W, 2 * self.rows), dtype=torch.float32, device=S.device)
+        keys = out.get("maxkeys")
+        if keys is None:
+            keys = torch.empty(2 * max(B, 1), dtype=torch.int32, device=S.device)
+        got = _lib.check(self.lib.smh_features_f32(self._h, _ptr(S), _ptr(harm), _ptr(perc), B, T, W or 0, shift or 0,
+                                                   _ptr(fv), _ptr(patches) if nP else None, _ptr(keys), _stream()),
+                         "smh_features_f32")
+        assert got == nP
+        return {"fv": fv, "patches": patches, "n_patches": nP, "maxkeys": keys}
+
+    # ---- fused fast path ----
+    def run(self, audio, W=None, shift=None, taps=False, out=None):
+        """audio (B, n_samples) -> dict(fv=(B, 2*rows, T)[, patches=(B*nP, W, 2*rows)][, S, harm, perc]).
+        `out` may carry preallocated 'fv' / 'patches' tensors (steady-state loops allocate nothing)."""
+        audio = _f32c(audio, "audio")
+        B, N = audio.shape
+        T = self.num_frames(N)
+        if T < 1:
+            raise ValueError("clip of %d samples is shorter than n_fft=%d" % (N, self.cfg.n_fft))
+        dev = audio.device
+        out = {} if out is None else out
+        fv = out.get("fv")
+        if fv is None or fv.shape != (B, 2 * self.rows, T):
+            fv = torch.empty((B, 2 * self.rows, T), dtype=torch.float32, device=dev)
+        patches, nP = None, 0
+        if W is not None:
+            nP = self.num_patches(T, W, shift)
+            patches = out.get("patches")
+            if patches is None or patches.shape != (B * nP, W, 2 * self.rows):
+                patches = torch.empty((B * nP, W, 2 * self.rows), dtype=torch.float32, device=dev)
+        need = self.lib.smh_frontend_workspace_bytes(self._h, B, N)
+        if self._work is None or self._work.numel() < need or self._work.device != dev:
+            self._work = torch.empty(need, dtype=torch.uint8, device=dev)
+        S = harm = perc = None
+        if taps:
+            S = torch.empty((B, self.K, T), dtype=torch.float32, device=dev)
+            harm, perc = torch.empty_like(S), torch.empty_like(S)
+        got = _lib.check(self.lib.smh_frontend_f32(
+            self._h, _ptr(audio), B, N, W or 0, shift or 0, _ptr(fv), _ptr(patches) if nP else None,
+            _ptr(self._work), self._work.numel(), _ptr(S), _ptr(harm), _ptr(perc), _stream()), "smh_frontend_f32")
+        assert got == nP, (got, nP)
+        res = {"fv": fv, "n_patches": nP}
+        if W is not None:
+            res["patches"] = patches
+        if taps:
+            res.update(S=S, harm=harm, perc=perc)
+        return res

@@ -1,0 +1,179 @@
+"""B3_MTL host object: a Keras-style facade (`predict`, `get_weights`, `save_weights`, `to_json`, ...) over
+the `smh_model` C ABI.  Mirrors what the reference's drivers call on the object returned by
+`get_Lemaire_MTL_model` (lib/proposed_architectures.py:85-170; Proposed_Work_Results.py:345-374,520,586).
+
+Weights are kept on the host as float32 numpy arrays in CANONICAL order (Keras array layouts):
+  tcn/initial_conv kernel (1,F,32), bias (32)
+  per (stack s, dilation d): conv kernel (3,32,32), bias, conv1x1 kernel (1,32,32), bias
+  3C kernel (T*32, n_classes), bias
+  per head (S, M, [N,] R): dense kernel (T*32,16), bias, BN gamma, beta, moving_mean, moving_variance,
+                           out kernel (16, odim), out bias
+and uploaded (re-packed into MFMA operand order by libsmh) whenever they change.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def head_spec(n_classes: int):
+    """(name, out_dim, activation) of the auxiliary heads in Keras output order
+    (proposed_architectures.py:25-80,154; 5_class_classification.py:150-215,286)."""
+    if n_classes == 5:
+        return [("S", 1, "sigmoid"), ("M", 1, "sigmoid"), ("N", 1, "sigmoid"), ("R", 3, "linear")]
+    return [("S", 1, "sigmoid"), ("M", 1, "sigmoid"), ("R", 2, "linear")]
+
+
+def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_stacks=3, n_dil=8):
+    """Ordered (name, shape, fan_in, fan_out|None) in canonical order; fan_out None -> not glorot."""
+    Cf, D = nb_filters, patch_size * nb_filters
+    spec = [("tcn/initial_conv/kernel", (1, n_feat, Cf), n_feat, Cf), ("tcn/initial_conv/bias", (Cf,), 0, None)]
+    for s in range(nb_stacks):
+        for i in range(n_dil):
+            p = "tcn/s%d_d%d" % (s, 2 ** i)
+            spec += [(p + "/conv/kernel", (kernel_size, Cf, Cf), kernel_size * Cf, kernel_size * Cf),
+                     (p + "/conv/bias", (Cf,), 0, None),
+                     (p + "/conv1x1/kernel", (1, Cf, Cf), Cf, Cf), (p + "/conv1x1/bias", (Cf,), 0, None)]
+    spec += [("3C/kernel", (D, n_classes), D, n_classes), ("3C/bias", (n_classes,), 0, None)]
+    for name, odim, _ in head_spec(n_classes):
+        spec += [(name + "/dense/kernel", (D, 16), D, 16), (name + "/dense/bias", (16,), 0, None),
+                 (name + "/bn/gamma", (16,), 1, None), (name + "/bn/beta", (16,), 0, None),
+                 (name + "/bn/moving_mean", (16,), 0, None), (name + "/bn/moving_variance", (16,), 1, None),
+                 (name + "/out/kernel", (16, odim), 16, odim), (name + "/out/bias", (odim,), 0, None)]
+    return spec
+
+
+class B3MTL:
+    """`model` object of get_Lemaire_MTL_model.  Inference runs entirely in libsmh (HIP)."""
+
+    def __init__(self, n_feat=240, patch_size=68, n_classes=3, TR_STEPS=1, loss_weights=None, seed=None,
+                 nb_filters=32, kernel_size=3, nb_stacks=3, n_dilations=8):
+        self.lib = _lib.require_gpu()
+        self.n_feat, self.patch_size, self.n_classes = int(n_feat), int(patch_size), int(n_classes)
+        self.nb_filters, self.kernel_size, self.nb_stacks, self.n_dilations = nb_filters, kernel_size, nb_stacks, n_dilations
+        self.TR_STEPS, self.loss_weights = TR_STEPS, loss_weights
+        rng = np.random.default_rng(seed)
+        # proposed_architectures.py:136 draws the (training-only) spatial dropout rate at build time
+        self.dropout_rate = float(rng.uniform(0.05, 0.5))
+        self.initial_learning_rate = 0.002
+        cfg = _lib.ModelCfg(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
+        h = C.c_void_p()
+        _lib.check(self.lib.smh_model_create(C.byref(cfg), C.byref(h)), "smh_model_create")
+        self._h = h
+        self.out_dim = self.lib.smh_model_out_dim(self._h)
+        self._spec = weight_spec(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
+        self.weights = OrderedDict()
+        for name, shape, fan_in, fan_out in self._spec:  # Keras defaults: glorot_uniform / zeros / BN ones
+            if fan_out is not None:
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                self.weights[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            else:
+                self.weights[name] = np.full(shape, float(fan_in), np.float32)
+        assert self.count_params() == self.lib.smh_model_num_params(self._h)
+        self._dirty = True
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.smh_model_destroy(h)
+            self._h = None
+
+    # ---- Keras-style surface -----------------------------------------------------------------
+    @property
+    def output_names(self):
+        return [n for n, _, _ in head_spec(self.n_classes)] + ["3C"]
+
+    @property
+    def metrics_names(self):
+        """Proposed_Work_Results.py:887 expects ['loss','S_loss','M_loss','R_loss','3C_loss','3C_accuracy']."""
+        return ["loss"] + [n + "_loss" for n in self.output_names] + ["3C_accuracy"]
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for _, s, _, _ in self._spec))
+
+    def get_weights(self):
+        return [self.weights[n].copy() for n, _, _, _ in self._spec]
+
+    def set_weights(self, arrays):
+        arrays = list(arrays)
+        if len(arrays) != len(self._spec):
+            raise ValueError("set_weights: expected %d arrays, got %d" % (len(self._spec), len(arrays)))
+        for (name, shape, _, _), a in zip(self._spec, arrays):
+            a = np.asarray(a, dtype=np.float32)
+            if a.shape != tuple(shape):
+                raise ValueError("set_weights: %s expects shape %s, got %s" % (name, shape, a.shape))
+            self.weights[name] = a.copy()
+        self._dirty = True
+
+    def set_weights_dict(self, d):
+        self.set_weights([d[n] for n, _, _, _ in self._spec])
+
+    def save_weights(self, path):
+        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **{k.replace("/", "__"): v for k, v in self.weights.items()})
+
+    def load_weights(self, path):
+        p = path if str(path).endswith(".npz") else str(path) + ".npz"
+        with np.load(p) as z:
+            self.set_weights_dict({k.replace("__", "/"): z[k] for k in z.files})
+
+    def to_json(self):
+        return json.dumps({"class_name": "B3_MTL", "config": {
+            "n_feat": self.n_feat, "patch_size": self.patch_size, "n_classes": self.n_classes,
+            "nb_filters": self.nb_filters, "kernel_size": self.kernel_size, "nb_stacks": self.nb_stacks,
+            "n_dilations": self.n_dilations, "dropout_rate": self.dropout_rate, "outputs": self.output_names}})
+
+    def summary(self, print_fn=print):
+        print_fn("Model: B3_MTL (Lemaire et al. TCN + MTL heads), input (None, %d, %d)" % (self.patch_size, self.n_feat))
+        for name, shape, _, _ in self._spec:
+            print_fn("  %-40s %-18s %d" % (name, str(tuple(shape)), int(np.prod(shape))))
+        print_fn("Total params: %d" % self.count_params())
+
+    # ---- inference -----------------------------------------------------------------------------
+    def _sync_weights(self):
+        if self._dirty:
+            flat = np.concatenate([self.weights[n].ravel() for n, _, _, _ in self._spec]).astype(np.float32)
+            _lib.check(self.lib.smh_model_set_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "smh_model_set_weights")
+            self._dirty = False
+
+    def forward_device(self, x, out=None, trunk=None):
+        """x: float32 CUDA tensor (N, W, n_feat) -> (N, out_dim) tensor [S|M|(N)|R|3C] on the device."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+            raise TypeError("forward_device expects a float32 CUDA tensor")
+        x = x.contiguous()
+        if x.dim() != 3 or x.shape[1] != self.patch_size or x.shape[2] != self.n_feat:
+            raise ValueError("expected input (N, %d, %d), got %s" % (self.patch_size, self.n_feat, tuple(x.shape)))
+        self._sync_weights()
+        N = x.shape[0]
+        if out is None:
+            out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.smh_model_forward_f32(
+            self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
+            None if trunk is None else C.c_void_p(trunk.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_f32")
+        return out
+
+    def split_outputs(self, out):
+        """(N, out_dim) -> list in Keras output order [S, M, (N,) R, 3C]."""
+        res, col = [], 0
+        for _, odim, _ in head_spec(self.n_classes):
+            res.append(out[:, col:col + odim])
+            col += odim
+        res.append(out[:, col:col + self.n_classes])
+        return res
+
+    def predict(self, x, batch_size=None, verbose=0):
+        """model.predict(x=batchData) -> [S, M, (N,) R, 3C] numpy arrays (Proposed_Work_Results.py:520,586)."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+        elif x.dtype != torch.float32:
+            x = x.float()
+        out = self.forward_device(x.cuda())
+        return [o.cpu().numpy() for o in self.split_outputs(out)]

@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports every symbol include/smh.h declares, the integer contracts
+match the oracle / compiled reference, the product never touches oracle/, and the compute path fails
+loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _lib():
+    from sm_hpss_mtl_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsmh.so not built (run __graft_entry__.build())")
+    return _lib
+
+
+def test_header_symbols_exported_and_typed():
+    _l = _lib()
+    lib = _l.load()
+    hdr = open(os.path.join(ROOT, "include", "smh.h")).read()
+    declared = set(re.findall(r"\b(smh_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), "declared in smh.h but not exported: " + name
+    assert declared == set(_l.SIGNATURES), declared ^ set(_l.SIGNATURES)
+    assert lib.smh_version() >= 100
+
+
+def test_integer_contracts_match_oracle(golden_fe):
+    from oracle import frontend as ofe
+    lib = _lib().load()
+    for N in (0, 399, 400, 559, 560, 16000, 16159, 48000):
+        assert lib.smh_num_frames(N, 400, 160) == ofe.num_frames(N, 400, 160)
+    for T, W, shift, nP in golden_fe["npatch_table"]:
+        T, W, shift = int(T), int(W), int(shift)
+        assert lib.smh_num_patches(T, W, shift) == nP
+        starts = ofe.patch_starts(T, W, shift)
+        assert [lib.smh_patch_start(T, W, shift, p) for p in range(len(starts))] == starts
+    for T, W in ((98, 249), (98, 99), (98, 98), (98, 68), (10, 68), (68, 68), (34, 68)):
+        assert lib.smh_tiled_frames(T, W) == ofe.tile_if_short(np.zeros((1, T)), W).shape[1]
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[/.]_ref|libsmh_oracle", re.M)
+    for base in ("sm_hpss_mtl_amd", "lib"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dp, f), errors="replace").read()
+                    assert not pat.search(src), "product file references the oracle: " + os.path.join(dp, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read() if os.path.exists(os.path.join(ROOT, "bench.py")) else ""
+    for m in re.finditer(r"^\s*(from|import)\s+oracle\b.*$", bench, re.M):
+        # allowed only inside the cpu_baseline function
+        head = bench[:m.start()]
+        last_def = re.findall(r"^def (\w+)", head, re.M)[-1]
+        assert last_def == "cpu_baseline", "bench.py imports oracle outside cpu_baseline(): " + m.group(0)
+
+
+def test_reference_module_paths_importable():
+    import importlib
+    for mod in ("lib.preprocessing", "lib.cython_impl.tools", "lib.proposed_architectures"):
+        m = importlib.import_module(mod)
+    import lib.preprocessing as pp
+    for fn in ("get_featuregram", "get_feature_patches", "normalize_signal", "mix_signals", "load_and_preprocess_signal"):
+        assert callable(getattr(pp, fn))
+    import lib.proposed_architectures as pa
+    assert callable(pa.get_Lemaire_MTL_model)
+    import lib.cython_impl.tools as tl
+    assert callable(tl.extract_patches)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _lib()
+    from sm_hpss_mtl_amd.frontend import Frontend
+    from sm_hpss_mtl_amd.model import B3MTL
+    with pytest.raises(RuntimeError, match="GPU|HIP"):
+        Frontend()
+    with pytest.raises(RuntimeError, match="GPU|HIP"):
+        B3MTL()
+
+
+def test_host_signal_helpers_match_oracle():
+    from oracle import frontend as ofe
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    rng = np.random.default_rng(1)
+    sp = rng.standard_normal(5000).astype(np.float32)
+    mu = rng.standard_normal(1700).astype(np.float32)
+    np.testing.assert_allclose(pp.normalize_signal(sp), ofe.normalize_signal(sp), rtol=0, atol=0)
+    for db in (-5, 0, 10, 20):
+        a, b = pp.mix_signals(sp, mu, db), ofe.mix_signals(sp, mu, db)
+        assert a.dtype == np.float32 and a.shape == (5000,)
+        np.testing.assert_allclose(a, b, atol=1e-6)
+        assert abs(np.max(np.abs(a)) - 1) < 1e-6
+
+
+def test_weight_spec_matches_oracle_order():
+    from oracle import b3_mtl
+    from sm_hpss_mtl_amd.model import weight_spec
+    for ncls, W in ((3, 68), (5, 68), (3, 249)):
+        w = b3_mtl.init_weights(seed=0, patch_size=W, n_classes=ncls)
+        spec = weight_spec(240, W, ncls)
+        assert [n for n, _, _, _ in spec] == list(w.keys())
+        assert [tuple(s) for _, s, _, _ in spec] == [v.shape for v in w.values()]

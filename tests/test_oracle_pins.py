@@ -1,0 +1,141 @@
+"""CPU: pin the oracle against the boundary routines the reference delegates to and against the
+committed golden vectors.  No GPU, no product code."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import b3_mtl, frontend as ofe
+from tests.conftest import ROOT, checks
+
+
+def test_median_vs_scipy_bit_exact():
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(3)
+    S = np.abs(rng.standard_normal((201, 98))).astype(np.float32)
+    S[5:9, 10:40] = 0.25  # ties
+    for w in (3, 11, 17, 21, 51):
+        assert np.array_equal(ofe.median_time(S, w), ndi.median_filter(S, size=(1, w), mode="reflect"))
+        assert np.array_equal(ofe.median_freq(S, w), ndi.median_filter(S, size=(w, 1), mode="reflect"))
+    # window longer than the axis (multiple reflections)
+    small = np.abs(rng.standard_normal((7, 5))).astype(np.float32)
+    assert np.array_equal(ofe.median_time(small, 21), ndi.median_filter(small, size=(1, 21), mode="reflect"))
+    assert np.array_equal(ofe.median_freq(small, 21), ndi.median_filter(small, size=(21, 1), mode="reflect"))
+
+
+def test_c_oracle_median_and_patches():
+    so = os.path.join(ROOT, "oracle", "_build", "libsmh_oracle.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle C library not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(4)
+    S = np.abs(rng.standard_normal((40, 33))).astype(np.float32)
+    out = np.empty_like(S)
+    fp = ctypes.POINTER(ctypes.c_float)
+    for w in (5, 11, 21):
+        assert lib.orc_median_time(S.ctypes.data_as(fp), out.ctypes.data_as(fp), 40, 33, w) == 0
+        assert np.array_equal(out, ofe.median_time(S, w))
+        assert lib.orc_median_freq(S.ctypes.data_as(fp), out.ctypes.data_as(fp), 40, 33, w) == 0
+        assert np.array_equal(out, ofe.median_freq(S, w))
+    FV = rng.standard_normal((6, 120)).astype(np.float32)
+    for W, shift in ((68, 34), (99, 24), (5, 1)):
+        nP = lib.orc_num_patches(120, W, shift)
+        po = np.empty((nP, 6, W))
+        assert lib.orc_extract_patches(FV.ctypes.data_as(fp), po.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 6, 120, W, shift) == nP
+        assert np.array_equal(po, ofe.extract_patches(FV, W, shift))
+
+
+def test_patches_vs_compiled_reference_module():
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not any(f.startswith("tools") and f.endswith(".so") for f in (os.listdir(ref_dir) if os.path.isdir(ref_dir) else [])):
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, ref_dir)
+    try:
+        tools = importlib.import_module("tools")
+    finally:
+        sys.path.remove(ref_dir)
+    rng = np.random.default_rng(5)
+    for T in (69, 98, 137, 300):
+        FV = rng.standard_normal((9, T)).astype(np.float32)
+        for W, shift in ((68, 68), (68, 34), (99, 34), (249, 24)):
+            FVt = ofe.tile_if_short(FV, W)
+            ref = tools.extract_patches(FVt, FVt.shape, W, shift)
+            got = ofe.extract_patches(FVt, W, shift)
+            assert ref.dtype == got.dtype == np.float64 and np.array_equal(ref, got), (T, W, shift)
+
+
+def test_npatch_table_golden(golden_fe):
+    for T, W, shift, nP in golden_fe["npatch_table"]:
+        assert len(ofe.patch_starts(int(T), int(W), int(shift))) == nP, (T, W, shift)
+
+
+def test_standardize_vs_sklearn(golden_fe):
+    skp = pytest.importorskip("sklearn.preprocessing")
+    fv = golden_fe["fv"]
+    half = fv.shape[0] // 2
+    for rows in (fv[:half], fv[half:]):
+        ref = skp.StandardScaler(copy=True).fit_transform(rows.T.copy()).T
+        got = ofe.standardize_rows(rows)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, ref, atol=2e-6, rtol=0)
+    # constant row (the empty mel filter) -> zeros
+    const = np.full((1, 98), -37.5, np.float32)
+    assert np.all(ofe.standardize_rows(const) == 0)
+
+
+def test_frontend_golden_roundtrip(golden_fe, clips4):
+    """The committed vectors are what the oracle produces today (guards against silent oracle drift)."""
+    assert np.allclose(checks(clips4[0]), golden_fe["audio0_check"], rtol=1e-12)
+    fv, p = ofe.featuregram(clips4[0], "LogMelHarmPercSpec", return_parts=True)
+    assert np.array_equal(p["harm"], golden_fe["harm_21"]) and np.array_equal(p["perc"], golden_fe["perc_11"])
+    np.testing.assert_allclose(p["S"], golden_fe["S"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(fv, golden_fe["fv"], atol=1e-4)
+    np.testing.assert_allclose(ofe.standardize_rows(fv[:120]), golden_fe["std_H"], atol=1e-5)
+
+
+def test_closed_form_identities(clips4):
+    fv, p = ofe.featuregram(clips4[1], "LogMelHarmPercSpec", return_parts=True)
+    S, H, P = p["S"], p["H"], p["P"]
+    assert S.shape == (201, 98) and fv.shape == (240, 98) and fv.dtype == np.float32
+    assert np.all(np.abs(H + P - S) <= 2 * np.spacing(S) + 1e-30)  # masks sum to one
+    assert np.all(H >= 0) and np.all(P >= 0)
+    for half in (fv[:120], fv[120:]):
+        assert half.max() - half.min() <= 80.0 + 1e-4  # top_db clip per array
+    B = ofe.mel_basis()
+    assert B.shape == (120, 201) and np.all(B >= 0)
+    assert np.count_nonzero(B) == 393 and (B.sum(axis=1) == 0).sum() == 1  # 393 nnz, 1 empty filter
+    # frames: T = 1 + (N - n_fft)//hop
+    assert ofe.num_frames(16000, 400, 160) == 98 and ofe.num_frames(399, 400, 160) == 0
+    # tile-if-short quirk: T < W tiles until T > W (98 -> 294 for W=249, 98 -> 196 for W=99)
+    assert ofe.tile_if_short(np.zeros((2, 98)), 249).shape[1] == 294
+    assert ofe.tile_if_short(np.zeros((2, 98)), 99).shape[1] == 196
+    assert ofe.tile_if_short(np.zeros((2, 98)), 98).shape[1] == 98
+
+
+def test_b3mtl_golden_and_shapes(golden_model):
+    for ncls, W in ((3, 68), (5, 68), (3, 99)):
+        w = b3_mtl.init_weights(seed=7, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+        x = np.random.default_rng(11).standard_normal((6, W, 240)).astype(np.float32)
+        outs = b3_mtl.forward(x, w, n_classes=ncls)
+        got = np.concatenate(outs, axis=1)
+        np.testing.assert_allclose(got, golden_model["out_c%d_W%d" % (ncls, W)], atol=1e-5)
+        assert np.allclose(outs[-1].sum(axis=1), 1, atol=1e-6) and outs[-1].shape == (6, ncls)
+    n3 = sum(v.size for v in b3_mtl.init_weights(patch_size=68).values())
+    # 218 743 params at W=68 of which 3*16*2 are non-trainable BN moving statistics
+    assert n3 - 3 * 32 == 218743
+    assert abs(b3_mtl.flops_per_patch() - 14.64e6) < 0.01e6
+
+
+def test_b3mtl_dilated_conv_matches_torch():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 30, 8)).astype(np.float32)
+    k = rng.standard_normal((3, 8, 5)).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    for d in (1, 4, 16, 64):
+        ref = torch.nn.functional.conv1d(torch.from_numpy(x).permute(0, 2, 1), torch.from_numpy(k).permute(2, 1, 0),
+                                         torch.from_numpy(b), padding=d, dilation=d).permute(0, 2, 1).numpy()
+        np.testing.assert_allclose(b3_mtl.conv1d_same(x, k, b, d), ref, atol=1e-5)

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs,
+against the committed golden vectors, and -- at BASELINE's full batch -- through size-independent
+properties.  Tolerances are SURVEY 8(d'): bit-exact for selection/indexing, stated fp32 bounds elsewhere."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import b3_mtl, frontend as ofe
+from tests.conftest import checks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    return Frontend(FrontendConfig())
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1 STFT
+# ---------------------------------------------------------------------------------------------------
+def test_stft_mag_vs_oracle(fe, clips4, golden_fe):
+    S = host(fe.stft_mag(dev(clips4)))
+    assert S.shape == (4, 201, 98) and S.dtype == np.float32  # frame count is an integer contract
+    for i in range(4):
+        ref = ofe.stft_mag(clips4[i])
+        assert np.max(np.abs(S[i] - ref)) <= 1e-5 * ref.max()  # rel 1e-5 of max|S| per clip
+    assert np.max(np.abs(S[0] - golden_fe["S"])) <= 1e-5 * golden_fe["S"].max()
+
+
+def test_stft_other_lengths_and_nfft(clips4):
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    f512 = Frontend(FrontendConfig(n_fft=512, win_length=400, n_mels=0, log_db=True))  # Jang: zero-padded window
+    y = clips4[:2, :5000]
+    S = host(f512.stft_mag(dev(y)))
+    assert S.shape == (2, 257, 1 + (5000 - 512) // 160)
+    for i in range(2):
+        ref = ofe.stft_mag(y[i], n_fft=512, win_length=400, hop=160)
+        assert np.max(np.abs(S[i] - ref)) <= 1e-5 * ref.max()
+    with pytest.raises(ValueError):
+        f512.stft_mag(dev(clips4[:1, :300]))  # shorter than n_fft
+
+
+# ---------------------------------------------------------------------------------------------------
+# a2 median filters: bit-exact selection
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lh,lp", [(21, 11), (17, 17), (11, 51), (31, 31), (13, 7), (3, 63)])
+def test_hpss_median_bit_exact(fe, clips4, lh, lp):
+    S = np.stack([ofe.stft_mag(c) for c in clips4])
+    harm, perc = fe.hpss_median(dev(S), lh, lp)
+    harm, perc = host(harm), host(perc)
+    for i in range(4):
+        assert np.array_equal(harm[i], ofe.median_time(S[i], lh)), "harm differs"
+        assert np.array_equal(perc[i], ofe.median_freq(S[i], lp)), "perc differs"
+
+
+def test_median_golden_scipy(fe, golden_fe):
+    S = golden_fe["S"][None]
+    harm, perc = fe.hpss_median(dev(S), 21, 11)
+    assert np.array_equal(host(harm)[0], golden_fe["harm_21"])  # scipy.ndimage.median_filter outputs
+    assert np.array_equal(host(perc)[0], golden_fe["perc_11"])
+    h17, p17 = fe.hpss_median(dev(S), 17, 17)
+    assert np.array_equal(host(h17)[0][::25], golden_fe["harm_17_rows"])
+    assert np.array_equal(host(p17)[0][::25], golden_fe["perc_17_rows"])
+    assert np.allclose(checks(host(h17)[0]), golden_fe["harm_17_check"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("K,T", [(201, 98), (257, 97), (201, 1000), (201, 37), (40, 300), (201, 5), (3, 98), (1, 1)])
+def test_median_ragged_shapes_ties_and_tiny_axes(fe, K, T):
+    """Long files (frame tiling + halo), odd sizes, heavy ties and axes shorter than the window."""
+    rng = np.random.default_rng(K * 1000 + T)
+    S = np.abs(rng.standard_normal((2, K, T))).astype(np.float32)
+    S[0] = np.round(S[0] * 4) / 4  # many exact ties
+    S[1, : max(1, K // 3)] = 0.0  # zero rows (split_zeros territory)
+    for w in (21, 11):
+        ht = host(fe.median_time(dev(S), w))
+        pf = host(fe.median_freq(dev(S), w))
+        for i in range(2):
+            assert np.array_equal(ht[i], ofe.median_time(S[i], w)), ("time", K, T, w)
+            assert np.array_equal(pf[i], ofe.median_freq(S[i], w)), ("freq", K, T, w)
+
+
+def test_median_rejects_bad_windows(fe):
+    S = dev(np.ones((1, 20, 20), np.float32))
+    with pytest.raises(ValueError):
+        fe.median_time(S, 4)  # even
+    with pytest.raises(ValueError):
+        fe.median_freq(S, 65)  # > SMH_MAX_MEDIAN
+    assert fe.median_time(torch.empty((0, 20, 20), device="cuda"), 5).shape == (0, 20, 20)  # empty batch
+
+
+# ---------------------------------------------------------------------------------------------------
+# a3-a6 masks, mel, dB, featuregram
+# ---------------------------------------------------------------------------------------------------
+def test_softmask_bit_exact_given_inputs(fe, golden_fe):
+    S, harm, perc = golden_fe["S"], golden_fe["harm_21"], golden_fe["perc_11"]
+    S2 = np.stack([S, S]); h2 = np.stack([harm, harm]); p2 = np.stack([perc, perc])
+    h2[1, :3] = 0; p2[1, :3] = 0  # both below tiny -> mask 0.5 each
+    H, P = fe.softmask(dev(S2), dev(h2), dev(p2))
+    H, P = host(H), host(P)
+    for i in range(2):
+        mh, mp = ofe.softmask(h2[i], p2[i]), ofe.softmask(p2[i], h2[i])
+        assert np.array_equal(H[i], S2[i] * mh) and np.array_equal(P[i], S2[i] * mp)  # same f32 op order
+    assert np.array_equal(H[0], golden_fe["H"]) and np.array_equal(P[0], golden_fe["P"])
+    assert np.all(np.abs(H + P - S2) <= 2 * np.spacing(S2) + 1e-30)
+
+
+def test_mel_basis_and_projection(fe, golden_fe):
+    B = fe.mel_basis()
+    assert B.shape == (120, 201)
+    np.testing.assert_allclose(B, golden_fe["mel_basis"], rtol=2e-7, atol=0)  # same float64 construction
+    assert np.array_equal(B == 0, golden_fe["mel_basis"] == 0)
+    Y = host(fe.mel(dev(golden_fe["H"][None])))[0]
+    ref = ofe.mel_project(golden_fe["H"], 120)
+    np.testing.assert_allclose(Y, ref, rtol=1e-5, atol=1e-6 * ref.max())
+
+
+def test_power_to_db(fe):
+    rng = np.random.default_rng(2)
+    X = np.abs(rng.standard_normal((3, 120, 98))).astype(np.float32) * np.float32(10.0) ** rng.uniform(-8, 2, (3, 1, 1)).astype(np.float32)
+    X[0, 0] = 0  # hits amin
+    Y = host(fe.power_to_db_sq(dev(X)))
+    for i in range(3):
+        ref = ofe.power_to_db(X[i] ** 2)
+        np.testing.assert_allclose(Y[i], ref, atol=1e-3)  # abs 1e-3 dB
+        assert abs(Y[i].min() - (Y[i].max() - 80)) < 1e-3 or Y[i].min() > Y[i].max() - 80
+
+
+@pytest.mark.parametrize("feat", ["LogMelHarmPercSpec", "MelHarmPercSpec", "HarmPercSpec", "LogHarmPercSpec"])
+def test_featuregram_fused_vs_oracle(clips4, feat):
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    PARAMS = {"Tw": 25, "Ts": 10, "Model": "Lemaire_et_al_MTL", "l_harm": {"Lemaire_et_al_MTL": 21},
+              "l_perc": {"Lemaire_et_al_MTL": 11}, "frame_level_scaling": False}
+    res = pp.featuregram_batch(PARAMS, dev(clips4), 400, 120, feat, taps=True)
+    fv, S, harm, perc = host(res["fv"]), host(res["S"]), host(res["harm"]), host(res["perc"])
+    for i in range(4):
+        ref, p = ofe.featuregram(clips4[i], feat, return_parts=True)
+        assert fv[i].shape == ref.shape and fv.dtype == np.float32
+        # medians are exact selections of the GPU's own S
+        assert np.array_equal(harm[i], ofe.median_time(S[i], 21)) and np.array_equal(perc[i], ofe.median_freq(S[i], 11))
+        if feat.startswith("Log"):
+            # dB domain: abs 1e-3 except where the top-dB / amin floors clip (compare clipped-or-equal)
+            half = ref.shape[0] // 2
+            for a, b in ((fv[i][:half], ref[:half]), (fv[i][half:], ref[half:])):
+                floor = b.max() - 80
+                free = (b > floor + 0.05) & (a > floor + 0.05)
+                assert np.max(np.abs(a[free] - b[free])) < 2e-2, feat
+                assert np.mean(np.abs(a - b) < 1e-3) > 0.98
+                assert abs(a.max() - b.max()) < 1e-3
+        else:
+            np.testing.assert_allclose(fv[i], ref, rtol=2e-4, atol=2e-5 * p["S"].max())
+
+
+def test_featuregram_golden_and_per_file_wrapper(clips4, golden_fe, tmp_path):
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    PARAMS = {"Tw": 25, "Ts": 10, "Model": "Lemaire_et_al_MTL", "l_harm": {"Lemaire_et_al_MTL": 21},
+              "l_perc": {"Lemaire_et_al_MTL": 11}, "frame_level_scaling": False}
+    fv = pp.featuregram_from_signal(PARAMS, clips4[0], 400, 120, "LogMelHarmPercSpec")
+    assert fv.shape == (240, 98) and fv.dtype == np.float32
+    assert np.mean(np.abs(fv - golden_fe["fv"]) < 1e-3) > 0.98 and np.max(np.abs(fv - golden_fe["fv"])) < 0.5
+    # file-based call + the reference's .npy cache layout
+    wav = tmp_path / "clipA.npy"
+    np.save(wav, clips4[0])
+    a = pp.get_featuregram(PARAMS, "music", str(tmp_path / "feat"), "", str(wav), None, 400, 120, "LogMelHarmPercSpec")
+    assert (tmp_path / "feat" / "music" / "clipA.npy").exists()
+    b = pp.get_featuregram(PARAMS, "music", str(tmp_path / "feat"), "", str(wav), None, 400, 120, "LogMelHarmPercSpec")
+    assert np.array_equal(a, b) and np.max(np.abs(a - fv)) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# a7-a9 standardise + patches
+# ---------------------------------------------------------------------------------------------------
+def test_standardize_rows(fe, golden_fe):
+    fv = golden_fe["fv"]
+    Y = host(fe.standardize_rows(dev(fv)))
+    np.testing.assert_allclose(Y[:120], golden_fe["std_H"], atol=1e-4)  # sklearn StandardScaler outputs
+    np.testing.assert_allclose(Y[120:], golden_fe["std_P"], atol=1e-4)
+    const = np.full((2, 50), 3.25, np.float32)
+    assert np.all(host(fe.standardize_rows(dev(const))) == 0)
+
+
+@pytest.mark.parametrize("W,shift", [(68, 68), (68, 34), (99, 34), (249, 24), (5, 1)])
+def test_extract_patches_indexing_bit_exact(fe, golden_fe, W, shift):
+    fv = golden_fe["fv"][:120]
+    ref = ofe.extract_patches(ofe.tile_if_short(fv, W), W, shift)  # == compiled tools.pyx (pinned on CPU)
+    got = host(fe.extract_patches(dev(fv[None]), W, shift))
+    assert got.shape == ref.shape and np.array_equal(got.astype(np.float64), ref)
+    tm = host(fe.extract_patches(dev(fv[None]), W, shift, time_major=True))
+    assert np.array_equal(tm, np.transpose(got, (0, 2, 1)))
+    key = "patches_W%d_s%d_shape" % (W, shift)
+    if key in golden_fe:
+        assert tuple(golden_fe[key]) == got.shape
+        assert np.allclose(checks(got), golden_fe["patches_W%d_s%d_check" % (W, shift)], rtol=1e-6)
+
+
+@pytest.mark.parametrize("W,shift", [(68, 68), (68, 34), (99, 34), (249, 24)])
+def test_get_feature_patches_wrapper_vs_oracle(golden_fe, W, shift):
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    from sm_hpss_mtl_amd.lib.cython_impl import tools
+    fv = golden_fe["fv"]
+    PARAMS = {"frame_level_scaling": False, "Model": "Lemaire_et_al_MTL"}
+    got = pp.get_feature_patches(PARAMS, fv.copy(), W, shift, "LogMelHarmPercSpec")
+    ref = ofe.feature_patches(fv, W, shift, "LogMelHarmPercSpec")
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=1e-4)
+    got4 = pp.get_feature_patches({"frame_level_scaling": False, "Model": "Doukhan_et_al_MTL"}, fv.copy(), W, shift, "MelHarmPercSpec")
+    assert got4.shape == ref.shape + (1,)
+    p = tools.extract_patches(fv, fv.shape, 68, 34)
+    assert p.dtype == np.float64 and np.array_equal(p, ofe.extract_patches(fv, 68, 34))
+    if (W, shift) == (68, 34):
+        assert np.array_equal(p[:, :8, :].astype(np.float32), golden_fe["patches_W68_s34_first8rows"])  # compiled tools.pyx
+
+
+@pytest.mark.parametrize("W,shift", [(68, 68), (99, 34), (249, 24)])
+def test_fused_patches_vs_oracle(fe, clips4, W, shift):
+    res = fe.run(dev(clips4), W=W, shift=shift)
+    fv, patches = host(res["fv"]), host(res["patches"])
+    nP = res["n_patches"]
+    assert patches.shape == (4 * nP, W, 240)
+    for i in range(4):
+        ref = ofe.tcn_input(ofe.feature_patches(fv[i], W, shift, "LogMelHarmPercSpec"))  # from the GPU's own fv
+        np.testing.assert_allclose(patches[i * nP:(i + 1) * nP], ref, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a10-a12 B3_MTL forward
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ncls,W,N", [(3, 68, 6), (5, 68, 6), (3, 99, 6), (3, 249, 3), (3, 68, 1030)])
+def test_b3mtl_forward_vs_oracle(golden_model, ncls, W, N):
+    from sm_hpss_mtl_amd.model import B3MTL
+    w = b3_mtl.init_weights(seed=7, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls)
+    m.set_weights_dict(w)
+    x = np.random.default_rng(11).standard_normal((N, W, 240)).astype(np.float32)
+    trunk = torch.empty((N, W, 32), device="cuda")
+    out = host(m.forward_device(dev(x), trunk=trunk))
+    n_ref = min(N, 12)
+    sel = np.r_[0:n_ref // 2, N - (n_ref - n_ref // 2):N]
+    ref_outs, ref_trunk = b3_mtl.forward(x[sel], w, n_classes=ncls, return_trunk=True)
+    ref = np.concatenate(ref_outs, axis=1)
+    np.testing.assert_allclose(host(trunk)[sel], ref_trunk, atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(out[sel], ref, atol=1e-4)  # SURVEY 8(d'): abs 1e-4
+    assert np.array_equal(out[sel][:, -ncls:].argmax(1), ref[:, -ncls:].argmax(1))
+    key = "out_c%d_W%d" % (ncls, W)
+    if N == 6 and key in golden_model:
+        np.testing.assert_allclose(out, golden_model[key], atol=1e-4)
+    outs = m.predict(x[:5])
+    assert [o.shape[1] for o in outs] == ([1, 1, 2, 3] if ncls == 3 else [1, 1, 1, 3, 5])
+    assert np.allclose(outs[-1].sum(1), 1, atol=1e-5)
+
+
+def test_get_lemaire_model_surface(tmp_path):
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
+    model, lr = get_Lemaire_MTL_model(TR_STEPS=100, N_MELS=240, n_classes=3, patch_size=68, seed=3)
+    assert lr == 0.002 and model.count_params() == 218743 + 96
+    assert model.metrics_names == ["loss", "S_loss", "M_loss", "R_loss", "3C_loss", "3C_accuracy"]
+    lines = []
+    model.summary(print_fn=lines.append)
+    assert any("Total params" in s for s in lines) and "B3_MTL" in model.to_json()
+    x = np.random.default_rng(0).standard_normal((4, 68, 240))
+    a = model.predict(x)
+    model.save_weights(str(tmp_path / "w"))
+    m2, _ = get_Lemaire_MTL_model(100, 240, 3, 68, seed=99)
+    m2.load_weights(str(tmp_path / "w"))
+    for u, v in zip(a, m2.predict(x)):
+        assert np.array_equal(u, v)
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((2, 67, 240), np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# full BASELINE size: properties that do not need the oracle
+# ---------------------------------------------------------------------------------------------------
+def test_full_batch_properties(fe):
+    from sm_hpss_mtl_amd.synth import synth_clips
+    B = 1024
+    clips = synth_clips(64, seed=1)
+    audio = dev(np.tile(clips, (B // 64, 1)))
+    res = fe.run(audio, W=68, shift=68, taps=True)
+    S, harm, perc, fv, patches = res["S"], res["harm"], res["perc"], res["fv"], res["patches"]
+    torch.cuda.synchronize()
+    assert patches.shape == (B, 68, 240) and torch.isfinite(patches).all() and torch.isfinite(fv).all()
+    # replicas of the same clip give identical bits wherever they sit in the batch
+    for t in (S, harm, perc, fv, patches):
+        v = t.view(B // 64, 64, -1)
+        assert torch.equal(v[0], v[-1]) and torch.equal(v[0], v[7])
+    # medians are selections: every output value occurs in its input row / column window range
+    assert (harm <= S.amax(dim=2, keepdim=True)).all() and (harm >= S.amin(dim=2, keepdim=True)).all()
+    assert (perc <= S.amax(dim=1, keepdim=True)).all() and (perc >= S.amin(dim=1, keepdim=True)).all()
+    # median filtering commutes with positive scaling, bit for bit (power of two)
+    h2, p2 = fe.hpss_median(S * 4.0)
+    assert torch.equal(h2, harm * 4.0) and torch.equal(p2, perc * 4.0)
+    # top-dB: each half spans at most 80 dB; standardised patches have ~zero mean / unit variance per row
+    assert float((fv[:, :120].amax(dim=(1, 2)) - fv[:, :120].amin(dim=(1, 2))).max()) <= 80.0 + 1e-3
+    # bit-exact against the oracle on a handful of clips spread over the batch
+    Sh, hh, ph = host(S), host(harm), host(perc)
+    for i in (0, 63, 511, 1023):
+        assert np.array_equal(hh[i], ofe.median_time(Sh[i], 21)) and np.array_equal(ph[i], ofe.median_freq(Sh[i], 11))
