@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on synthetic 1 s @ 16 kHz clips.
+
+One "step" = one pass of the whole hot path over one batch that is already resident in HBM:
+  STFT -> HPSS medians (l_harm x l_perc) -> soft masks -> mel -> dB -> standardise -> patches (W=68)
+       -> B3_MTL forward (logits)
+Workload = BASELINE.json configs[1] (batch 1024 x 1 s clips, 17x17 medians) carried through the
+network forward, i.e. the metric "clips/sec HPSS+MTL-CNN fwd".  N>1: one process per GPU (launched by
+torch.distributed.run), every rank owns its own 1024 clips -- clips are independent units, so there is
+no collective on the data path (weak scaling); only the timing barrier/all-reduce uses RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step; per-kernel
+figures for every stage are in `kernels`.  `cpu_baseline` times the numpy oracle ("port") on a bounded
+sample of the same workload on this host (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E spec peak (6.29 TB/s measured copy ceiling)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (= vector peak)
+# algorithmic bytes / flops per clip, SURVEY 8(d) (K=201 bins, T=98 frames, 240 features, W=68)
+K_BINS, T_FRAMES, FEAT, W_PATCH = 201, 98, 240, 68
+BYTES = {
+    "stft": 16000 * 4 + K_BINS * T_FRAMES * 4,                       # audio in, |S| out          142,792
+    "median": 3 * K_BINS * T_FRAMES * 4,                             # S in, harm+perc out        236,376
+    "features": 3 * K_BINS * T_FRAMES * 4 + 2 * FEAT * T_FRAMES * 4 + W_PATCH * FEAT * 4,  # S,h,p in; fv out, re-read; patches out
+}
+FLOPS_MODEL = 2.0 * (W_PATCH * FEAT * 32 + 24 * W_PATCH * (3 * 32 * 32 + 32 * 32) + W_PATCH * 32 * 51)  # 14.64 MFLOP
+
+
+def cpu_baseline(clips, l_harm, l_perc, seed=0, budget_s=12.0):
+    """Oracle ("port": numpy restatement calling the same numpy/scipy-level routines librosa delegates to)
+    timed on the host cores of this box, single process, on a bounded sample of the same clips."""
+    from oracle import b3_mtl, frontend as ofe  # the checker, used here only as the CPU baseline
+    weights = b3_mtl.init_weights(seed=seed)
+
+    def one(y):
+        fv = ofe.featuregram(y, "LogMelHarmPercSpec", l_harm=l_harm, l_perc=l_perc)
+        x = ofe.tcn_input(ofe.feature_patches(fv, W_PATCH, W_PATCH))
+        return b3_mtl.forward(x, weights)
+
+    t0 = time.perf_counter()
+    one(clips[0])
+    per = time.perf_counter() - t0
+    n = int(max(2, min(len(clips), budget_s / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(clips[i])
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": 1, "kind": "port",
+            "sample": "%d of the same synthetic clips, numpy oracle front end (%dx%d) + numpy B3_MTL forward, 1 process" % (n, l_harm, l_perc)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step")
+    ap.add_argument("--l-harm", type=int, default=17)
+    ap.add_argument("--l-perc", type=int, default=17)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    from sm_hpss_mtl_amd.model import B3MTL
+    from sm_hpss_mtl_amd.sharding import shard_range
+    from sm_hpss_mtl_amd.synth import synth_clips
+
+    B = args.batch
+    # weak scaling: the job is world*B clips; rank r owns the contiguous index range shard_range(...)
+    lo, hi = shard_range(world * B, rank, world)
+    assert hi - lo == B
+    base = synth_clips(64, seed=1000 + rank)  # 64 distinct clips per rank, tiled to the batch
+    audio = torch.from_numpy(np.tile(base, ((B + 63) // 64, 1))[:B]).cuda()
+
+    fe = Frontend(FrontendConfig(l_harm=args.l_harm, l_perc=args.l_perc))
+    model = B3MTL(n_feat=FEAT, patch_size=W_PATCH, n_classes=3, seed=0)
+    T = fe.num_frames(audio.shape[1])
+    dev = audio.device
+    S = torch.empty((B, fe.K, T), device=dev)
+    harm, perc = torch.empty_like(S), torch.empty_like(S)
+    feat_out = {"fv": torch.empty((B, FEAT, T), device=dev), "patches": torch.empty((B, W_PATCH, FEAT), device=dev),
+                "maxkeys": torch.empty(2 * B, dtype=torch.int32, device=dev)}
+    logits = torch.empty((B, model.out_dim), device=dev)
+    trunk = torch.empty((B, W_PATCH, 32), device=dev)
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    lib, h = fe.lib, fe._h
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    names = ["stft", "median", "features", "model"]
+    ev = None
+
+    def step(record=None):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if record is not None:
+            record[0].record()
+        _lib.check(lib.smh_stft_mag_f32(h, p(audio), B, audio.shape[1], p(S), st))
+        if record is not None:
+            record[1].record()
+        _lib.check(lib.smh_hpss_median_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), st))
+        if record is not None:
+            record[2].record()
+        fe.features(S, harm, perc, W=W_PATCH, shift=W_PATCH, out=feat_out)
+        if record is not None:
+            record[3].record()
+        model.forward_device(feat_out["patches"], out=logits, trunk=trunk)
+        if record is not None:
+            record[4].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # HIP events on the launch stream (torch's current stream IS the stream every kernel is launched on)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(logits).all(), "non-finite logits"
+
+    ms = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
+    kernels = {}
+    for n in ("stft", "median", "features"):
+        gbs = BYTES[n] * B / (ms[n] * 1e-3) / 1e9
+        kernels[n] = {"ms": round(ms[n], 4), "bound": "hbm", "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    tf = FLOPS_MODEL * B / (ms["model"] * 1e-3) / 1e12
+    kernels["model"] = {"ms": round(ms["model"], 4), "bound": "mfma", "achieved_TFLOPs": round(tf, 2),
+                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    dominant = max(names, key=lambda n: ms[n])
+    if dominant == "model":
+        roof = {"kernel": "tcn_trunk_kernel+heads_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}
+    else:
+        kn = {"stft": "stft_mag_kernel", "median": "hpss_median_kernel", "features": "hp_feat_kernel+std_patch_kernel"}[dominant]
+        roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kernels[dominant]["frac"], "traffic": None}
+
+    if rank == 0:
+        clips_total = world * B * args.steps
+        res = {
+            "metric": "clips/sec HPSS+MTL-CNN fwd (1s@16kHz)", "value": round(clips_total / elapsed, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x 1s@16kHz clips per GPU: STFT(400/160) -> HPSS %dx%d median + soft mask -> logmel(120) "
+                                   "-> standardise -> patch W=68 -> B3_MTL(3-class) forward" % (B, args.l_harm, args.l_perc),
+                       "clips_per_gpu": B, "l_harm": args.l_harm, "l_perc": args.l_perc, "patch": W_PATCH, "sharding": "per-clip, no data-path collective"},
+            "roofline": roof, "kernels": kernels,
+            "hbm_roofline_pct_median_kernel": round(100 * kernels["median"]["frac"], 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(base, args.l_harm, args.l_perc)
+            res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

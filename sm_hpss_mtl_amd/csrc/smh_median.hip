@@ -134,7 +134,7 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
 }
 
 int check_args(const void *S, int B, int K, int T, int w, const char *name) {
-    SMH_REQUIRE(S != nullptr, "%s: null input", name);
+    SMH_REQUIRE(S != nullptr || B == 0, "%s: null input", name);
     SMH_REQUIRE(B >= 0 && K >= 1 && T >= 1, "%s: bad shape B=%d K=%d T=%d", name, B, K, T);
     SMH_REQUIRE(w >= 1 && w <= SMH_MAX_MEDIAN && (w & 1), "%s: window must be odd in [1,%d], got %d", name,
                 SMH_MAX_MEDIAN, w);
@@ -151,7 +151,7 @@ extern "C" int smh_median_time_f32(const smh_ctx *, const float *d_S, int B, int
                                    void *stream) {
     int rc = check_args(d_S, B, K, T, l_harm, "smh_median_time_f32");
     if (rc) return rc;
-    SMH_REQUIRE(d_harm, "smh_median_time_f32: null output");
+    SMH_REQUIRE(d_harm || B == 0, "smh_median_time_f32: null output");
     if (B == 0) return SMH_OK;
     hipStream_t st = (hipStream_t)stream;
     if (l_harm == 1) {
@@ -166,7 +166,7 @@ extern "C" int smh_median_freq_f32(const smh_ctx *, const float *d_S, int B, int
                                    void *stream) {
     int rc = check_args(d_S, B, K, T, l_perc, "smh_median_freq_f32");
     if (rc) return rc;
-    SMH_REQUIRE(d_perc, "smh_median_freq_f32: null output");
+    SMH_REQUIRE(d_perc || B == 0, "smh_median_freq_f32: null output");
     if (B == 0) return SMH_OK;
     hipStream_t st = (hipStream_t)stream;
     if (l_perc == 1) {
@@ -183,7 +183,7 @@ extern "C" int smh_hpss_median_f32(const smh_ctx *, const float *d_S, int B, int
     if (rc) return rc;
     rc = check_args(d_S, B, K, T, l_perc, "smh_hpss_median_f32");
     if (rc) return rc;
-    SMH_REQUIRE(d_harm && d_perc, "smh_hpss_median_f32: null output");
+    SMH_REQUIRE((d_harm && d_perc) || B == 0, "smh_hpss_median_f32: null output");
     if (B == 0) return SMH_OK;
     if (fast_ok(T, l_harm) && fast_ok(K, l_perc) && find_pair_kernel(l_harm, l_perc))
         return launch(d_S, B, K, T, l_harm, l_perc, d_harm, d_perc, (hipStream_t)stream);
