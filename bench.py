@@ -122,10 +122,11 @@ def main():
         _lib.check(lib.smh_stft_mag_f32(h, p(audio), B, audio.shape[1], p(S), st))
         if record is not None:
             record[1].record()
-        _lib.check(lib.smh_hpss_median_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), st))
+        lay = _lib.check(lib.smh_hpss_median_ex_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), 1, st))
         if record is not None:
             record[2].record()
-        fe.features(S, harm, perc, W=W_PATCH, shift=W_PATCH, out=feat_out)
+        _lib.check(lib.smh_features_ex_f32(h, p(S), p(harm), p(perc), lay, B, T, W_PATCH, W_PATCH, p(feat_out["fv"]),
+                                           p(feat_out["patches"]), p(feat_out["maxkeys"]), st))
         if record is not None:
             record[3].record()
         model.forward_device(feat_out["patches"], out=logits, trunk=trunk)

@@ -83,6 +83,14 @@ int smh_median_time_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int 
 int smh_median_freq_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_perc, float *d_perc,
                         void *stream);
 
+/* Layout-aware variants used by the fused pipeline (no reference counterpart: the reference never
+ * materialises harm on a device).  harm_layout 0 = (B,K,T) as above; 1 = (B,T,K) time-major, which lets
+ * the harmonic lanes (one per bin) store coalesced -- about 30 us per 1024 clips faster on MI355X.
+ * smh_hpss_median_ex_f32 returns the layout it actually wrote (it falls back to 0 for window pairs or
+ * tiny axes outside the fused kernel table); pass that value on to smh_features_ex_f32.              */
+int smh_hpss_median_ex_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_harm, int l_perc,
+                           float *d_harm, float *d_perc, int harm_layout, void *stream);
+
 /* ---- a3: H = S*softmask(harm,perc), P = S*softmask(perc,harm); power=2, split_zeros=True ---- */
 int smh_softmask_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, size_t n,
                      float *d_H, float *d_P, void *stream);
@@ -113,6 +121,9 @@ int smh_extract_patches_f32(const smh_ctx *ctx, const float *d_FV, int B, int F,
  * Returns nP per clip.                                                                            */
 int smh_features_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int B, int T,
                      int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys, void *stream);
+/* same, with d_harm in the layout returned by smh_hpss_median_ex_f32 */
+int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int harm_layout,
+                        int B, int T, int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys, void *stream);
 
 /* ---- fused fast path: get_featuregram (from Xin) + get_feature_patches for a batch of clips ---
  * d_audio (B, n_samples) -> d_fv (B, 2*rows, T)  [the featuregram, = get_featuregram's return]

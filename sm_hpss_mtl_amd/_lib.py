@@ -39,6 +39,7 @@ SIGNATURES = {
     "smh_patch_start": (_i, [_i, _i, _i, _i]),
     "smh_stft_mag_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "smh_hpss_median_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
+    "smh_hpss_median_ex_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp]),
     "smh_median_time_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "smh_median_freq_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "smh_softmask_f32": (_i, [_vp, _fp, _fp, _fp, _sz, _fp, _fp, _vp]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "smh_standardize_rows_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "smh_extract_patches_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),
     "smh_features_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
+    "smh_features_ex_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
     "smh_frontend_workspace_bytes": (_sz, [_vp, _i, _i]),
     "smh_frontend_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _fp, _fp, _fp, _vp]),
     "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),

@@ -13,10 +13,17 @@ struct MelTable {
 MelTable mel_table(const smh_ctx *c);
 
 // (S, harm, perc) -> featuregram fv (B, 2*rows, T) with un-clipped dB values + per-array max keys
-int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int B, int T, float *fv,
-                   int *maxkeys, float *H, float *P, hipStream_t st);
+// harm_tmajor != 0: harm is (B, T, K) as written by smh_median::launch_hpss(want_tmajor = 1)
+int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,
+                   float *fv, int *maxkeys, hipStream_t st);
 // top_db clip (in place) + StandardScaler + time-major patches
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
                      float *patches, hipStream_t st);
 
 }  // namespace smh_feat
+
+namespace smh_median {
+// both HPSS medians in one launch; returns 1 if harm was written time-major (B,T,K), 0 if (B,K,T), <0 on error
+int launch_hpss(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, int want_tmajor,
+                hipStream_t st);
+}  // namespace smh_median

@@ -159,9 +159,13 @@ __global__ void extract_patches_kernel(const float *__restrict__ FV, int F, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// fused fast path, kernel 1: (S, harm, perc) slab -> soft masks -> H,P in LDS -> mel -> dB (unclipped)
-// grid (time slabs, B).  The per-array top_db maximum is accumulated with one atomicMax per workgroup
-// and applied by std_patch_kernel, which owns whole featuregram halves.
+// fused fast path, kernel 1: (S, harm, perc) -> soft masks -> mel -> dB (un-clipped), grid (frame slabs, B).
+// One thread per output (mel row m, frame t), frames fastest, so S / perc rows are read coalesced and
+// each thread recomputes the masks of the <= 11 bins of its filter (every bin is shared by ~2 filters:
+// the re-reads are L1/L2 hits, HBM traffic stays 1x).  `harm` may arrive time-major (B,T,K) from the
+// median kernel (coalesced harmonic stores); the slab is then transposed through LDS (odd row stride).
+// The per-array top_db maximum is accumulated with one atomicMax per workgroup and applied by
+// std_patch_kernel, which owns whole featuregram halves.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ordered_key(float f) {
     const int b = __float_as_int(f);
@@ -169,46 +173,71 @@ __device__ __forceinline__ int ordered_key(float f) {
 }
 __device__ __forceinline__ float key_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-__global__ void __launch_bounds__(256)
+constexpr int kFeatThreads = 512;
+
+__global__ void __launch_bounds__(kFeatThreads)
 hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, const float *__restrict__ harm,
-               const float *__restrict__ perc, int K, int T, int TS, int rows, float *__restrict__ fv,
-               int *__restrict__ maxkeys, float *__restrict__ Hout, float *__restrict__ Pout) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int smax[2 * 4];
+               const float *__restrict__ perc, int harm_tmajor, int K, int T, int TS, int rows, float *__restrict__ fv,
+               int *__restrict__ maxkeys) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];  // [TS][KP] harmonic slab (time-major input only)
+    __shared__ int smax[2 * (kFeatThreads / 64)];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * TS;
     const int nt = min(TS, T - t0);
-    const int ld = TS | 1;
-    float *Hs = lds, *Ps = lds + (size_t)K * ld;
+    const int KP = K | 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const size_t cb = (size_t)b * K * T;
-    for (int i = threadIdx.x; i < K * nt; i += blockDim.x) {
-        const int k = i / nt, c = i - k * nt;
-        const size_t g = cb + (size_t)k * T + t0 + c;
-        float hv, pv;
-        hpss_masks(S[g], harm[g], perc[g], hv, pv);
-        Hs[k * ld + c] = hv;
-        Ps[k * ld + c] = pv;
-        if (Hout) Hout[g] = hv;
-        if (Pout) Pout[g] = pv;
+    if (harm_tmajor) {
+        constexpr int kB = 4;
+        for (int c0 = wave; c0 < nt; c0 += nw * kB) {
+            for (int kb = 0; kb < K; kb += 64) {
+                float v[kB];
+                const int k = kb + lane;
+#pragma unroll
+                for (int r = 0; r < kB; ++r) {
+                    const int c = min(c0 + r * nw, nt - 1);
+                    v[r] = harm[cb + (size_t)(t0 + c) * K + min(k, K - 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < kB; ++r) {
+                    const int c = c0 + r * nw;
+                    if (c < nt && k < K) hs[c * KP + k] = v[r];
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float mxH = -FLT_MAX, mxP = -FLT_MAX;
     float *fvH = fv + (size_t)b * 2 * rows * T + t0;
     float *fvP = fvH + (size_t)rows * T;
+    const float *Sb = S + cb + t0, *Pb = perc + cb + t0, *Hb = harm + cb + t0;
     for (int i = threadIdx.x; i < rows * nt; i += blockDim.x) {
         const int m = i / nt, c = i - m * nt;
-        float aH, aP;
+        int k0 = m, cnt = 1;
+        const float *w = nullptr;
         if (mel.n_mels > 0) {
-            const int k0 = mel.start[m], cnt = mel.count[m];
-            const float *w = mel.w + mel.off[m];
-            aH = 0.f, aP = 0.f;
-            for (int j = 0; j < cnt; ++j) {
-                aH = fmaf(w[j], Hs[(k0 + j) * ld + c], aH);
-                aP = fmaf(w[j], Ps[(k0 + j) * ld + c], aP);
+            k0 = mel.start[m], cnt = mel.count[m];
+            w = mel.w + mel.off[m];
+        }
+        float aH = 0.f, aP = 0.f;
+        for (int j = 0; j < cnt; j += 4) {
+            float sv[4], pv[4], hv[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // four taps of loads in flight
+                const int jj = min(j + u, cnt - 1);
+                const size_t g = (size_t)(k0 + jj) * T + c;
+                sv[u] = Sb[g];
+                pv[u] = Pb[g];
+                hv[u] = harm_tmajor ? hs[c * KP + k0 + jj] : Hb[g];
+                wv[u] = (j + u < cnt) ? (w ? w[jj] : 1.0f) : 0.f;
             }
-        } else {
-            aH = Hs[m * ld + c];
-            aP = Ps[m * ld + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float H, P;
+                hpss_masks(sv[u], hv[u], pv[u], H, P);
+                aH = fmaf(wv[u], H, aH);
+                aP = fmaf(wv[u], P, aP);
+            }
         }
         if (log_db) {
             aH = db_of_sq(aH);
@@ -225,12 +254,13 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
             kH = max(kH, __shfl_xor(kH, off));
             kP = max(kP, __shfl_xor(kP, off));
         }
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) smax[wave] = kH, smax[4 + wave] = kP;
+        if (lane == 0) smax[wave] = kH, smax[nw + wave] = kP;
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicMax(&maxkeys[2 * b], max(max(smax[0], smax[1]), max(smax[2], smax[3])));
-            atomicMax(&maxkeys[2 * b + 1], max(max(smax[4], smax[5]), max(smax[6], smax[7])));
+            int a = smax[0], c = smax[nw];
+            for (int q = 1; q < nw; ++q) a = max(a, smax[q]), c = max(c, smax[nw + q]);
+            atomicMax(&maxkeys[2 * b], a);
+            atomicMax(&maxkeys[2 * b + 1], c);
         }
     }
 }
@@ -239,7 +269,9 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
 // fused fast path, kernel 2: one workgroup per (clip, half): top_db clip (written back: the final
 // featuregram) -> StandardScaler per row -> time-major patches (B*nP, W, 2*rows) for the TCN.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kPatchThreads = 1024;
+
+__global__ void __launch_bounds__(kPatchThreads)
 std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ maxkeys, int rows, int T, int Ttiled, int W,
                  int shift, int nP, float *__restrict__ patches) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -247,18 +279,31 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
     const int ld = T | 1;
     float *g = fv + ((size_t)b * 2 + half) * rows * T;
     const float thr = log_db ? key_to_float(maxkeys[2 * b + half]) - kTopDb : -FLT_MAX;
-    for (int i = threadIdx.x; i < rows * T; i += blockDim.x) {
-        const int r = i / T, t = i - r * T;
-        float v = g[i];
-        if (log_db) {
-            v = fmaxf(v, thr);
-            g[i] = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // rows in batches: loads first, then clip / write-back / LDS
+    constexpr int kB = 4;
+    for (int r0 = wave; r0 < rows; r0 += nw * kB) {
+        for (int tb = 0; tb < T; tb += 64) {
+            float v[kB];
+            const int t = tb + lane;
+#pragma unroll
+            for (int q = 0; q < kB; ++q) v[q] = g[(size_t)min(r0 + q * nw, rows - 1) * T + min(t, T - 1)];
+#pragma unroll
+            for (int q = 0; q < kB; ++q) {
+                const int r = r0 + q * nw;
+                if (r < rows && t < T) {
+                    float x = v[q];
+                    if (log_db) {
+                        x = fmaxf(x, thr);
+                        g[(size_t)r * T + t] = x;
+                    }
+                    tile[r * ld + t] = x;
+                }
+            }
         }
-        tile[r * ld + t] = v;
     }
     __syncthreads();
     if (!patches) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int r = wave; r < rows; r += nw) {
         float *row = tile + r * ld;
         double mean, scale;
@@ -274,7 +319,9 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
         float *o = patches + ((size_t)b * nP + p) * W * F + (size_t)half * rows;
         for (int i = threadIdx.x; i < W * rows; i += blockDim.x) {
             const int j = i / rows, f = i - j * rows;
-            o[(size_t)j * F + f] = tile[f * ld + (s + j) % T];
+            int tt = s + j;
+            tt -= (tt / T) * T;
+            o[(size_t)j * F + f] = tile[f * ld + tt];
         }
     }
 }
@@ -295,24 +342,22 @@ MelTable mel_table(const smh_ctx *c) {
     return m;
 }
 
-int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int B, int T, float *fv,
-                   int *maxkeys, float *H, float *P, hipStream_t st) {
+int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,
+                   float *fv, int *maxkeys, hipStream_t st) {
     const int K = c->K, rows = c->feat_rows;
-    // slab width: keep 2*K*(TS|1) floats under 64 KiB
-    int TS = (64 * 1024 / 4) / (2 * K);
-    if (TS > 32) TS = 32;
-    if ((TS & 1) == 0) TS -= 1;
-    if (TS < 1) return smh::set_error(SMH_E_INVALID, "K=%d too large for the feature kernel", K);
-    if (TS > T) TS = T;
-    const size_t lds = sizeof(float) * 2 * (size_t)K * (TS | 1);
+    // frame slabs: split T evenly into pieces of <= 64 frames (T=98 -> 2 x 49)
+    const int nslab = (T + 63) / 64;
+    const int TS = (T + nslab - 1) / nslab;
+    const size_t lds = harm_tmajor ? sizeof(float) * (size_t)TS * (K | 1) : 0;
+    if (lds > 150 * 1024) return smh::set_error(SMH_E_INVALID, "K=%d too large for the feature kernel", K);
     if (c->cfg.log_db) {
         hipLaunchKernelGGL(fill_int_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, maxkeys, 2 * B, (int)0x80000000);
         int rc = smh::launch_status("fill_int_kernel");
         if (rc) return rc;
     }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hp_feat_kernel, dim3((T + TS - 1) / TS, B), dim3(256), lds, st, mel_table(c), c->cfg.log_db, S, harm,
-                       perc, K, T, TS, rows, fv, maxkeys, H, P);
+    hipLaunchKernelGGL(hp_feat_kernel, dim3((T + TS - 1) / TS, B), dim3(kFeatThreads), lds, st, mel_table(c), c->cfg.log_db, S,
+                       harm, perc, harm_tmajor, K, T, TS, rows, fv, maxkeys);
     return smh::launch_status("hp_feat_kernel");
 }
 
@@ -323,7 +368,7 @@ int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int
     if (lds > 150 * 1024)
         return smh::set_error(SMH_E_INVALID, "clip of %d frames x %d rows exceeds the LDS tile of the patch kernel", T, rows);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(std_patch_kernel, dim3(2, B), dim3(256), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
+    hipLaunchKernelGGL(std_patch_kernel, dim3(2, B), dim3(kPatchThreads), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
                        smh_tiled_frames(T, W), W, shift, nP, patches);
     return smh::launch_status("std_patch_kernel");
 }

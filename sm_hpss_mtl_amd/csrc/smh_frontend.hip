@@ -10,11 +10,12 @@ namespace {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 }  // namespace
 
-extern "C" int smh_features_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int B,
-                                int T, int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys,
-                                void *stream) {
+extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc,
+                                   int harm_layout, int B, int T, int W, int shift, float *d_fv, float *d_patches,
+                                   int32_t *d_maxkeys, void *stream) {
     SMH_REQUIRE(ctx && d_S && d_harm && d_perc && d_fv && d_maxkeys, "smh_features_f32: null argument");
     SMH_REQUIRE(B >= 0 && B <= 65535 && T >= 1, "smh_features_f32: bad shape B=%d T=%d", B, T);
+    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_features_f32: harm_layout must be 0 or 1");
     int nP = 0;
     if (d_patches) {
         SMH_REQUIRE(W >= 1 && shift >= 1, "smh_features_f32: bad patch geometry W=%d shift=%d", W, shift);
@@ -22,13 +23,19 @@ extern "C" int smh_features_f32(const smh_ctx *ctx, const float *d_S, const floa
     }
     if (B == 0) return nP;
     hipStream_t st = (hipStream_t)stream;
-    int rc = smh_feat::launch_hp_feat(ctx, d_S, d_harm, d_perc, B, T, d_fv, (int *)d_maxkeys, nullptr, nullptr, st);
+    int rc = smh_feat::launch_hp_feat(ctx, d_S, d_harm, d_perc, harm_layout, B, T, d_fv, (int *)d_maxkeys, st);
     if (rc) return rc;
     // always run: it applies the top_db clip that completes the featuregram
     rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)d_maxkeys, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP,
                                     nP > 0 ? d_patches : nullptr, st);
     if (rc) return rc;
     return nP;
+}
+
+extern "C" int smh_features_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int B,
+                                int T, int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys,
+                                void *stream) {
+    return smh_features_ex_f32(ctx, d_S, d_harm, d_perc, 0, B, T, W, shift, d_fv, d_patches, d_maxkeys, stream);
 }
 
 extern "C" size_t smh_frontend_workspace_bytes(const smh_ctx *ctx, int B, int n_samples) {
@@ -55,11 +62,22 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
     float *harm = d_harm ? d_harm : (float *)(w + spec);
     float *perc = d_perc ? d_perc : (float *)(w + 2 * spec);
     int32_t *maxkeys = (int32_t *)(w + 3 * spec);
-    if (B > 0) {
-        int rc = smh_stft_mag_f32(ctx, d_audio, B, n_samples, S, stream);
-        if (rc) return rc;
-        rc = smh_hpss_median_f32(ctx, S, B, ctx->K, T, ctx->cfg.l_harm, ctx->cfg.l_perc, harm, perc, stream);
-        if (rc) return rc;
+    int nP = 0;
+    if (d_patches) {
+        SMH_REQUIRE(W >= 1 && shift >= 1, "smh_frontend_f32: bad patch geometry W=%d shift=%d", W, shift);
+        nP = smh_num_patches(smh_tiled_frames(T, W), W, shift);
     }
-    return smh_features_f32(ctx, S, harm, perc, B, T, W, shift, d_fv, d_patches, maxkeys, stream);
+    if (B == 0) return nP;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = smh_stft_mag_f32(ctx, d_audio, B, n_samples, S, stream);
+    if (rc) return rc;
+    // the harmonic median is written time-major (coalesced stores) unless the caller taps it
+    const int tm = smh_median::launch_hpss(S, B, ctx->K, T, ctx->cfg.l_harm, ctx->cfg.l_perc, harm, perc, d_harm ? 0 : 1, st);
+    if (tm < 0) return tm;
+    rc = smh_feat::launch_hp_feat(ctx, S, harm, perc, tm, B, T, d_fv, (int *)maxkeys, st);
+    if (rc) return rc;
+    rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)maxkeys, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP,
+                                    nP > 0 ? d_patches : nullptr, st);
+    if (rc) return rc;
+    return nP;
 }

@@ -1,4 +1,6 @@
 // Entry points of the HPSS median filters (kernel template: smh_median_kernel.h).
+#include <cstdlib>
+
 #include "smh_median_kernel.h"
 
 namespace smh_median {
@@ -95,6 +97,14 @@ int make_plan(int K, int T, int lh, int lp, Plan *p) {
     // segments: aim at similar lane-task lengths and <= 16 waves per workgroup
     const int nt = TT;
     int nsh = lh ? 2 : 0, nsp = lp ? 3 : 0;
+    // tuning override for experiments (tools/tune_median.py): SMH_MEDIAN_SEG="nsh,nsp"
+    if (const char *ev = getenv("SMH_MEDIAN_SEG")) {
+        int a = 0, b = 0;
+        if (sscanf(ev, "%d,%d", &a, &b) == 2) {
+            if (lh && a >= 1) nsh = a;
+            if (lp && b >= 1) nsp = b;
+        }
+    }
     if (lh && nt < 2 * lh) nsh = 1;
     if (lp && K < 6 * lp) nsp = 1;
     auto waves = [&](int n, int seg) { return seg ? (n * seg + 63) / 64 : 0; };
@@ -120,7 +130,8 @@ int launch_small(const float *S, int B, int K, int T, int w, int along_t, float 
     return smh::launch_status("median_small_kernel");
 }
 
-int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, hipStream_t st) {
+int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, hipStream_t st,
+           int harm_tmajor = 0) {
     KernelFn fn = (lh && lp) ? find_pair_kernel(lh, lp) : find_single_kernel(lh, lp);
     if (!fn) return smh::set_error(SMH_E_INVALID, "no median kernel for (l_harm,l_perc)=(%d,%d)", lh, lp);
     Plan p;
@@ -129,7 +140,7 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     dim3 grid(p.ntiles, B), block((p.nwh + p.nwp) * 64);
     hipLaunchKernelGGL(fn, grid, block, p.lds, st, S, harm, perc, K, T, p.TT, p.stride, p.nsh, p.nsp, p.nwh,
-                       -__builtin_inff(), __builtin_inff());
+                       harm_tmajor, -__builtin_inff(), __builtin_inff());
     return smh::launch_status("hpss_median_kernel");
 }
 
@@ -146,6 +157,20 @@ int check_args(const void *S, int B, int K, int T, int w, const char *name) {
 bool fast_ok(int n, int w) { return w >= 3 && w / 2 + 4 < n; }
 
 }  // namespace
+
+namespace smh_median {
+// Fused-pipeline entry: both filters in one launch, harm optionally time-major (B,T,K).
+// Returns 1 if the time-major layout was produced, 0 if the reference layout was used, <0 on error.
+int launch_hpss(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, int want_tmajor,
+                hipStream_t st) {
+    if (fast_ok(T, lh) && fast_ok(K, lp) && find_pair_kernel(lh, lp)) {
+        int rc = launch(S, B, K, T, lh, lp, harm, perc, st, want_tmajor);
+        return rc ? rc : (want_tmajor ? 1 : 0);
+    }
+    int rc = smh_hpss_median_f32(nullptr, S, B, K, T, lh, lp, harm, perc, (void *)st);
+    return rc ? rc : 0;
+}
+}  // namespace smh_median
 
 extern "C" int smh_median_time_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_harm, float *d_harm,
                                    void *stream) {
@@ -191,4 +216,16 @@ extern "C" int smh_hpss_median_f32(const smh_ctx *, const float *d_S, int B, int
     rc = smh_median_time_f32(nullptr, d_S, B, K, T, l_harm, d_harm, stream);
     if (rc) return rc;
     return smh_median_freq_f32(nullptr, d_S, B, K, T, l_perc, d_perc, stream);
+}
+
+extern "C" int smh_hpss_median_ex_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_harm, int l_perc,
+                                      float *d_harm, float *d_perc, int harm_layout, void *stream) {
+    int rc = check_args(d_S, B, K, T, l_harm, "smh_hpss_median_ex_f32");
+    if (rc) return rc;
+    rc = check_args(d_S, B, K, T, l_perc, "smh_hpss_median_ex_f32");
+    if (rc) return rc;
+    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_hpss_median_ex_f32: harm_layout must be 0 or 1");
+    SMH_REQUIRE((d_harm && d_perc) || B == 0, "smh_hpss_median_ex_f32: null output");
+    if (B == 0) return harm_layout;
+    return smh_median::launch_hpss(d_S, B, K, T, l_harm, l_perc, d_harm, d_perc, harm_layout, (hipStream_t)stream);
 }
