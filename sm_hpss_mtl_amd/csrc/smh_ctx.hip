@@ -104,7 +104,7 @@ static void build_mel_dense(double sr, int n_fft, int n_mels, std::vector<float>
 
 static int factor_radices(int M, int *radix) {
     int n = 0;
-    const int pref[] = {4, 2, 5, 3, 7};  // radices smh_stft.hip implements
+    const int pref[] = {8, 4, 2, 5, 3, 7};  // radices smh_stft.hip implements
     for (int p : pref) {
         while (M % p == 0 && M > 1) {
             if (n >= smh::kMaxFftStages) return -1;

@@ -4,8 +4,11 @@
 
 namespace smh_feat {
 
+constexpr int kMaxMels = 256;     // filters held in LDS by the fused feature kernel
+constexpr int kMaxMelNnz = 2048;  // taps held in LDS
+
 struct MelTable {
-    int n_mels;
+    int n_mels, nnz;
     const int *start, *count, *off;
     const float *w;
 };

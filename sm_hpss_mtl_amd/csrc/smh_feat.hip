@@ -28,6 +28,23 @@ __device__ __forceinline__ void hpss_masks(float s, float h, float p, float &H, 
     P = __fmul_rn(s, mp);
 }
 
+// Same masks for the FUSED path: hardware reciprocals (1 ulp) instead of IEEE divisions.  H and P are not
+// outputs there; the dB features they feed are compared at 1e-3 dB (SURVEY 8d').
+__device__ __forceinline__ void hpss_masks_fast(float s, float h, float p, float &H, float &P) {
+    float Z = fmaxf(h, p);
+    const bool bad = Z < FLT_MIN;
+    Z = bad ? 1.0f : Z;
+    const float iz = __builtin_amdgcn_rcpf(Z);
+    const float a = h * iz, b = p * iz;
+    const float m = a * a, r = b * b;
+    const float id = __builtin_amdgcn_rcpf(m + r);
+    float mh = m * id, mp = r * id;
+    mh = bad ? 0.5f : mh;
+    mp = bad ? 0.5f : mp;
+    H = s * mh;
+    P = s * mp;
+}
+
 __global__ void softmask_kernel(const float *__restrict__ S, const float *__restrict__ harm,
                                 const float *__restrict__ perc, size_t n, float *__restrict__ H,
                                 float *__restrict__ P) {
@@ -59,6 +76,10 @@ __global__ void mel_kernel(smh_feat::MelTable mel, const float *__restrict__ X, 
 __device__ __forceinline__ float db_of_sq(float x) {
     const float p = __fmul_rn(x, x);
     return 10.0f * log10f(fmaxf(kAmin, p));
+}
+// fused path: 10*log10(p) = 3.0103*log2(p) on the hardware log (abs error ~1e-6 dB)
+__device__ __forceinline__ float db_of_sq_fast(float x) {
+    return 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(kAmin, x * x));
 }
 
 template <typename Tv>
@@ -181,12 +202,17 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
                int *__restrict__ maxkeys) {
     extern __shared__ __attribute__((aligned(16))) float hs[];  // [TS][KP] harmonic slab (time-major input only)
     __shared__ int smax[2 * (kFeatThreads / 64)];
+    __shared__ int s_start[smh_feat::kMaxMels], s_cnt[smh_feat::kMaxMels], s_off[smh_feat::kMaxMels];
+    __shared__ float s_w[smh_feat::kMaxMelNnz];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * TS;
     const int nt = min(TS, T - t0);
     const int KP = K | 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const size_t cb = (size_t)b * K * T;
+    for (int i = threadIdx.x; i < mel.n_mels; i += blockDim.x) s_start[i] = mel.start[i], s_cnt[i] = mel.count[i], s_off[i] = mel.off[i];
+    for (int i = threadIdx.x; i < mel.nnz; i += blockDim.x) s_w[i] = mel.w[i];
+    if (!harm_tmajor) __syncthreads();
     if (harm_tmajor) {
         constexpr int kB = 4;
         for (int c0 = wave; c0 < nt; c0 += nw * kB) {
@@ -216,8 +242,8 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
         int k0 = m, cnt = 1;
         const float *w = nullptr;
         if (mel.n_mels > 0) {
-            k0 = mel.start[m], cnt = mel.count[m];
-            w = mel.w + mel.off[m];
+            k0 = s_start[m], cnt = s_cnt[m];
+            w = s_w + s_off[m];
         }
         float aH = 0.f, aP = 0.f;
         for (int j = 0; j < cnt; j += 4) {
@@ -234,14 +260,14 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float H, P;
-                hpss_masks(sv[u], hv[u], pv[u], H, P);
+                hpss_masks_fast(sv[u], hv[u], pv[u], H, P);
                 aH = fmaf(wv[u], H, aH);
                 aP = fmaf(wv[u], P, aP);
             }
         }
         if (log_db) {
-            aH = db_of_sq(aH);
-            aP = db_of_sq(aP);
+            aH = db_of_sq_fast(aH);
+            aP = db_of_sq_fast(aP);
             mxH = fmaxf(mxH, aH);
             mxP = fmaxf(mxP, aP);
         }
@@ -304,24 +330,47 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
     }
     __syncthreads();
     if (!patches) return;
-    for (int r = wave; r < rows; r += nw) {
-        float *row = tile + r * ld;
-        double mean, scale;
-        row_stats(T, lane, [&](int t) { return row[t]; }, mean, scale);
-        for (int t = lane; t < T; t += 64) row[t] = standardize(row[t], mean, scale);
+    // StandardScaler statistics: ONE THREAD PER ROW (rows are short; a wave-wide f64 reduction per row
+    // costs ~20x more instructions).  LDS reads are conflict-free: consecutive rows, odd row stride.
+    float *s_mean = tile + (size_t)rows * ld, *s_inv = s_mean + rows;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float *row = tile + r * ld;
+        double sum = 0.0;
+        for (int t = 0; t < T; ++t) sum += (double)row[t];
+        const double mean = sum / (double)T;
+        double q = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double dlt = (double)row[t] - mean;
+            q += dlt * dlt;
+        }
+        const double var = q / (double)T;
+        const double eps = 2.220446049250313e-16;
+        const double nm = (double)T * mean * eps;
+        const bool constant = var <= (double)T * eps * var + nm * nm;  // sklearn _is_constant_feature
+        double scale = sqrt(var);
+        if (constant || scale == 0.0) scale = 1.0;
+        s_mean[r] = (float)mean;
+        // keep the f64 mean exactly: store the low part too (mean = hi + lo)
+        s_inv[r] = (float)(1.0 / scale);
+        s_mean[rows + rows + r] = (float)(mean - (double)(float)mean);
     }
     __syncthreads();
+    const float *s_lo = s_mean + 2 * rows;
     const int F = 2 * rows;
     for (int p = 0; p < nP; ++p) {
         int s = p * shift;
         const int e = min(s + W, Ttiled);
         if (e - s < W) s = e - W;
         float *o = patches + ((size_t)b * nP + p) * W * F + (size_t)half * rows;
-        for (int i = threadIdx.x; i < W * rows; i += blockDim.x) {
-            const int j = i / rows, f = i - j * rows;
+        // one wave per frame j: lanes run over the feature rows (coalesced 480-byte stores)
+        for (int j = wave; j < W; j += nw) {
             int tt = s + j;
             tt -= (tt / T) * T;
-            o[(size_t)j * F + f] = tile[f * ld + tt];
+            for (int f = lane; f < rows; f += 64) {
+                // (x - mean) rounded to f32 as sklearn does (mean carried as hi + lo), then * 1/scale
+                const float c = (float)((double)tile[f * ld + tt] - ((double)s_mean[f] + (double)s_lo[f]));
+                o[(size_t)j * F + f] = c * s_inv[f];
+            }
         }
     }
 }
@@ -339,12 +388,15 @@ MelTable mel_table(const smh_ctx *c) {
     MelTable m;
     m.n_mels = c->n_mels;
     m.start = c->d_mel_start, m.count = c->d_mel_count, m.off = c->d_mel_off, m.w = c->d_mel_w;
+    m.nnz = c->mel_nnz;
     return m;
 }
 
 int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,
                    float *fv, int *maxkeys, hipStream_t st) {
     const int K = c->K, rows = c->feat_rows;
+    if (c->n_mels > smh_feat::kMaxMels || c->mel_nnz > smh_feat::kMaxMelNnz)
+        return smh::set_error(SMH_E_INVALID, "mel filterbank too large for the fused kernel (n_mels=%d nnz=%d)", c->n_mels, c->mel_nnz);
     // frame slabs: split T evenly into pieces of <= 64 frames (T=98 -> 2 x 49)
     const int nslab = (T + 63) / 64;
     const int TS = (T + nslab - 1) / nslab;
@@ -364,7 +416,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
                      float *patches, hipStream_t st) {
     const int rows = c->feat_rows;
-    const size_t lds = sizeof(float) * (size_t)rows * (T | 1);
+    const size_t lds = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows);
     if (lds > 150 * 1024)
         return smh::set_error(SMH_E_INVALID, "clip of %d frames x %d rows exceeds the LDS tile of the patch kernel", T, rows);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

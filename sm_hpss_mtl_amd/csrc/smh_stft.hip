@@ -5,17 +5,26 @@
 // complex sequence of length M = n_fft/2 (z[m] = x[2m] + i x[2m+1]), transformed by a mixed-radix
 // Stockham autosort FFT that lives entirely in LDS (ping-pong buffers, one butterfly per thread),
 // un-tangled into the n_fft/2+1 real-FFT bins and written as magnitudes, frame-fastest, so that the
-// (K, T) freq-major layout librosa returns is produced directly.  n_fft = 400 -> M = 200 = 4*2*5*5.
+// (K, T) freq-major layout librosa returns is produced directly.  n_fft = 400 -> M = 200 = 8*5*5.
+// Butterflies: radix 8 (= 2x4 in registers), radix 4, radix 2, Winograd radix 5, generic 3 / 7.
+// LDS indices are padded (one float2 per 16) so that the strided Stockham writes spread over banks;
+// work-item -> (frame, butterfly) maps use a reciprocal multiply instead of an integer division.
 // HBM traffic per clip: 64,000 B audio in (re-reads of the 2.5x frame overlap are served by L2),
 // 78,792 B magnitudes out.
 #include "smh_common.h"
 
 namespace {
 
+constexpr int kThreads = 256;
+
 struct StftArgs {
     int n_samples, n_fft, hop, M, K, T, tt;  // tt = frames per workgroup
     int n_stages;
     int radix[smh::kMaxFftStages];
+    float inv_nb[smh::kMaxFftStages];  // 1 / (M / radix)
+    float inv_ns[smh::kMaxFftStages];  // 1 / Ns of the stage
+    int tmul[smh::kMaxFftStages];      // M / (Ns * radix)
+    float inv_tt;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -23,10 +32,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by -i  (forward DFT quarter turn)
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // * (-i)
+__device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+// exact floor(it / n) for 0 <= it < 2^20 given inv = 1/n
+__device__ __forceinline__ int fdiv(int it, float inv) { return (int)(((float)it + 0.5f) * inv); }
 
-// generic small DFT for odd prime radices: out[q] = sum_r v[r] * w^(r q),  w = exp(-2 pi i / R)
 template <int R>
 __device__ __forceinline__ void dft_generic(float2 *v) {
     float2 o[R];
@@ -46,6 +56,15 @@ __device__ __forceinline__ void dft_generic(float2 *v) {
     for (int q = 0; q < R; ++q) v[q] = o[q];
 }
 
+__device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+    const float2 s0 = cadd(a, c), d0 = csub(a, c);
+    const float2 s1 = cadd(b, d), d1 = mul_mi(csub(b, d));
+    a = cadd(s0, s1);
+    b = cadd(d0, d1);
+    c = csub(s0, s1);
+    d = csub(d0, d1);
+}
+
 template <int R>
 __device__ __forceinline__ void dft(float2 *v) {
     if constexpr (R == 2) {
@@ -53,12 +72,36 @@ __device__ __forceinline__ void dft(float2 *v) {
         v[0] = cadd(a, b);
         v[1] = csub(a, b);
     } else if constexpr (R == 4) {
-        const float2 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
-        const float2 s1 = cadd(v[1], v[3]), d1 = mul_mi(csub(v[1], v[3]));
-        v[0] = cadd(s0, s1);
-        v[1] = cadd(d0, d1);
-        v[2] = csub(s0, s1);
-        v[3] = csub(d0, d1);
+        dft4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (R == 8) {
+        // 8 = 2 x 4: even/odd 4-point DFTs, odd outputs twisted by w8^k
+        float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4(e0, e1, e2, e3);
+        dft4(o0, o1, o2, o3);
+        const float h = 0.70710678118654752440f;
+        o1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));    // * (1 - i)/sqrt2
+        o2 = mul_mi(o2);                                           // * (-i)
+        o3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));   // * (-1 - i)/sqrt2
+        v[0] = cadd(e0, o0), v[4] = csub(e0, o0);
+        v[1] = cadd(e1, o1), v[5] = csub(e1, o1);
+        v[2] = cadd(e2, o2), v[6] = csub(e2, o2);
+        v[3] = cadd(e3, o3), v[7] = csub(e3, o3);
+    } else if constexpr (R == 5) {
+        // Winograd-style 5-point DFT: 34 real operations
+        const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+        const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+        const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+        const float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+        const float2 a1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+        const float2 a2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+        const float2 b1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        const float2 b2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        v[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+        v[1] = make_float2(a1.x + b1.y, a1.y - b1.x);  // a1 - i b1
+        v[4] = make_float2(a1.x - b1.y, a1.y + b1.x);  // a1 + i b1
+        v[2] = make_float2(a2.x + b2.y, a2.y - b2.x);
+        v[3] = make_float2(a2.x - b2.y, a2.y + b2.x);
     } else {
         dft_generic<R>(v);
     }
@@ -66,11 +109,9 @@ __device__ __forceinline__ void dft(float2 *v) {
 
 // One Stockham stage for butterfly j of one frame (Govindaraju et al. formulation).
 template <int R, bool FIRST>
-__device__ __forceinline__ void stage(const StftArgs &a, int j, int Ns, const float2 *__restrict__ src,
+__device__ __forceinline__ void stage(int step, int j, int Ns, float inv_ns, int tmul, const float2 *__restrict__ src,
                                       float2 *__restrict__ dst, const float2 *__restrict__ tw,
                                       const float *__restrict__ audio, const float *__restrict__ win) {
-    const int M = a.M;
-    const int step = M / R;
     float2 v[R];
     if constexpr (FIRST) {
         // read the windowed real frame straight from global memory: z[m] = (x[2m], x[2m+1])
@@ -80,47 +121,51 @@ __device__ __forceinline__ void stage(const StftArgs &a, int j, int Ns, const fl
             v[r] = make_float2(audio[2 * m] * win[2 * m], audio[2 * m + 1] * win[2 * m + 1]);
         }
     } else {
-        const int k = j % Ns;
-        const int tstep = k * (M / (Ns * R));  // exp(-2 pi i k r / (Ns R)) = twM[k r M/(Ns R)]
+        const int k = j - fdiv(j, inv_ns) * Ns;
+        const int tstep = k * tmul;  // exp(-2 pi i k r / (Ns R)) = twM[k r M/(Ns R)]
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float2 x = src[j + r * step];
+            float2 x = src[pad(j + r * step)];
             if (r > 0) x = cmul(x, tw[r * tstep]);
             v[r] = x;
         }
     }
     dft<R>(v);
-    const int k = FIRST ? 0 : j % Ns;
+    const int k = FIRST ? 0 : j - fdiv(j, inv_ns) * Ns;
     const int j0 = (j - k) * R + k;  // (j / Ns) * Ns * R + k
 #pragma unroll
-    for (int r = 0; r < R; ++r) dst[j0 + r * Ns] = v[r];
+    for (int r = 0; r < R; ++r) dst[pad(j0 + r * Ns)] = v[r];
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void run_stage(const StftArgs &a, int R, int j, int Ns, const float2 *src, float2 *dst,
-                                          const float2 *tw, const float *audio, const float *win) {
+__device__ __forceinline__ void run_stage(int nb, int R, int j, int Ns, float inv_ns, int tmul, const float2 *src,
+                                          float2 *dst, const float2 *tw, const float *audio, const float *win) {
     switch (R) {
-        case 2: stage<2, FIRST>(a, j, Ns, src, dst, tw, audio, win); break;
-        case 3: stage<3, FIRST>(a, j, Ns, src, dst, tw, audio, win); break;
-        case 4: stage<4, FIRST>(a, j, Ns, src, dst, tw, audio, win); break;
-        case 5: stage<5, FIRST>(a, j, Ns, src, dst, tw, audio, win); break;
-        case 7: stage<7, FIRST>(a, j, Ns, src, dst, tw, audio, win); break;
+        case 2: stage<2, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
+        case 3: stage<3, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
+        case 4: stage<4, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
+        case 5: stage<5, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
+        case 7: stage<7, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
+        case 8: stage<8, FIRST>(nb, j, Ns, inv_ns, tmul, src, dst, tw, audio, win); break;
         default: break;
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kThreads)
 stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__restrict__ window,
                 const float2 *__restrict__ twM, const float2 *__restrict__ tw2M, float *__restrict__ S) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int M = a.M, MP = M + 1;  // +1 float2 row padding: frame-fastest post-processing reads
-    float2 *tw = lds;               // M twiddles
-    float2 *buf0 = lds + M;
+    const int M = a.M;
+    const int MP = pad(M) + 2;  // padded frame stride (float2)
+    float2 *tw = lds;           // M twiddles
+    float2 *tw2 = lds + M;      // M + 1 untangle twiddles
+    float2 *buf0 = tw2 + (M + 1);
     float2 *buf1 = buf0 + a.tt * MP;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * a.tt;
     const int nf = min(a.tt, a.T - t0);
     for (int i = threadIdx.x; i < M; i += blockDim.x) tw[i] = twM[i];
+    for (int i = threadIdx.x; i <= M; i += blockDim.x) tw2[i] = tw2M[i];
     const float *clip = audio + (size_t)b * a.n_samples;
 
     float2 *src = buf0, *dst = buf1;
@@ -130,11 +175,11 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
         const int nb = M / R;
         __syncthreads();
         for (int it = threadIdx.x; it < nf * nb; it += blockDim.x) {
-            const int f = it / nb, j = it - f * nb;
+            const int f = fdiv(it, a.inv_nb[s]), j = it - f * nb;
             if (s == 0)
-                run_stage<true>(a, R, j, Ns, nullptr, dst + f * MP, tw, clip + (size_t)(t0 + f) * a.hop, window);
+                run_stage<true>(nb, R, j, Ns, 1.f, 0, nullptr, dst + f * MP, tw, clip + (size_t)(t0 + f) * a.hop, window);
             else
-                run_stage<false>(a, R, j, Ns, src + f * MP, dst + f * MP, tw, nullptr, nullptr);
+                run_stage<false>(nb, R, j, Ns, a.inv_ns[s], a.tmul[s], src + f * MP, dst + f * MP, tw, nullptr, nullptr);
         }
         float2 *tmp = src;
         src = dst;
@@ -144,15 +189,15 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
     __syncthreads();
     // real-FFT untangle + magnitude; frames fastest -> contiguous stores along t
     float *Sb = S + (size_t)b * a.K * a.T + t0;
+    const float inv_nf = nf == a.tt ? a.inv_tt : 1.0f / (float)nf;
     for (int it = threadIdx.x; it < nf * a.K; it += blockDim.x) {
-        const int k = it / nf, f = it - k * nf;
+        const int k = fdiv(it, inv_nf), f = it - k * nf;
         const float2 *Z = src + f * MP;
-        const float2 zk = Z[k == M ? 0 : k];
-        float2 zc = Z[k == 0 ? 0 : M - k];
+        const float2 zk = Z[pad(k == M ? 0 : k)];
+        float2 zc = Z[pad(k == 0 ? 0 : M - k)];
         zc.y = -zc.y;
         const float2 e = cadd(zk, zc), d = csub(zk, zc);
-        const float2 w = tw2M[k];
-        const float2 wd = cmul(w, d);  // X = 0.5*e - 0.5*i*w*d
+        const float2 wd = cmul(tw2[k], d);  // X = 0.5*e - 0.5*i*w*d
         const float re = 0.5f * (e.x + wd.y);
         const float im = 0.5f * (e.y - wd.x);
         Sb[(size_t)k * a.T + f] = __builtin_sqrtf(re * re + im * im);
@@ -163,7 +208,7 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
 
 extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, float *d_S,
                                 void *stream) {
-    SMH_REQUIRE(ctx && d_audio && d_S, "smh_stft_mag_f32: null argument");
+    SMH_REQUIRE(ctx && (d_audio || B == 0) && (d_S || B == 0), "smh_stft_mag_f32: null argument");
     SMH_REQUIRE(B >= 0 && B <= 65535, "smh_stft_mag_f32: B=%d out of range", B);
     const int T = smh_num_frames(n_samples, ctx->cfg.n_fft, ctx->cfg.hop);
     SMH_REQUIRE(T >= 1, "smh_stft_mag_f32: clip of %d samples is shorter than n_fft=%d", n_samples, ctx->cfg.n_fft);
@@ -171,16 +216,28 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
     StftArgs a;
     a.n_samples = n_samples, a.n_fft = ctx->cfg.n_fft, a.hop = ctx->cfg.hop, a.M = ctx->M, a.K = ctx->K, a.T = T;
     a.n_stages = ctx->n_stages;
-    for (int i = 0; i < smh::kMaxFftStages; ++i) a.radix[i] = i < ctx->n_stages ? ctx->radix[i] : 1;
+    for (int i = 0; i < smh::kMaxFftStages; ++i) {
+        a.radix[i] = i < ctx->n_stages ? ctx->radix[i] : 1;
+        a.inv_nb[i] = (float)a.radix[i] / (float)a.M;
+    }
+    for (int i = 0, ns = 1; i < smh::kMaxFftStages; ++i) {
+        a.inv_ns[i] = 1.0f / (float)ns;
+        a.tmul[i] = a.M / (ns * a.radix[i]) > 0 ? a.M / (ns * a.radix[i]) : 0;
+        ns *= a.radix[i];
+        if (ns > a.M) ns = a.M;
+    }
     // frames per workgroup: <= 16, chosen to split T evenly (T=98 -> 7 tiles of 14)
     const int max_tt = 16;
     const int ntiles = (T + max_tt - 1) / max_tt;
     a.tt = (T + ntiles - 1) / ntiles;
-    const size_t lds = sizeof(float2) * ((size_t)a.M + 2 * (size_t)a.tt * (a.M + 1));
+    a.inv_tt = 1.0f / (float)a.tt;
+    const int MP = a.M + (a.M >> 4) + 2;
+    const size_t lds = sizeof(float2) * ((size_t)a.M + (a.M + 1) + 2 * (size_t)a.tt * MP);
     SMH_REQUIRE(lds <= 150 * 1024, "smh_stft_mag_f32: n_fft=%d too large for the LDS FFT", a.n_fft);
+    SMH_REQUIRE((size_t)a.tt * a.K < (1u << 20), "smh_stft_mag_f32: tile too large");
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft_mag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    dim3 grid((T + a.tt - 1) / a.tt, B), block(256);
+    dim3 grid((T + a.tt - 1) / a.tt, B), block(kThreads);
     hipLaunchKernelGGL(stft_mag_kernel, grid, block, lds, (hipStream_t)stream, a, d_audio, ctx->d_window, ctx->d_twM,
                        ctx->d_tw2M, d_S);
     return smh::launch_status("stft_mag_kernel");

@@ -13,7 +13,11 @@
 //     to match the accumulator layout) -- no LDS round trip between the two convolutions,
 //   * bias and residual are folded into the accumulator initialisation.
 // One workgroup owns G patches; the activations x (G*T rows x 32 ch, fp32) live in LDS for all
-// 24 blocks (double buffered, one barrier per block); weights stream from L2 in MFMA A-operand order.
+// 24 blocks (double buffered, one barrier per block).  Weights stream from L2 in MFMA A-operand order
+// and are double-buffered in registers: block b+1's weights are requested before block b is computed.
+// The Dense layers that read the flattened trunk (3C logits + the Dense(16) of every head) run in the
+// same kernel as one more MFMA product D[output][patch] on the LDS-resident activations; BN / relu /
+// output Dense / sigmoid / softmax finish in a few threads.  One launch per forward.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -28,12 +32,15 @@ constexpr int C = 32;          // nb_filters (fixed by the MFMA tiling)
 constexpr int SX = 36;         // LDS row stride of x in floats (16-byte aligned rows)
 constexpr int kMaxHeads = 4;
 constexpr int kHidden = 16;    // Dense(16) of every MTL head
-constexpr int kHeadPatches = 4;  // patches per workgroup in the heads kernel
+constexpr int kMaxG = 16;      // patches per workgroup <= MFMA N
 constexpr float kNormEps = 1e-5f;
 constexpr float kBnEps = 1e-3f;
 
 struct TcnArgs {
-    int N, T, F, FQ, G, n_blocks, n_dil, vec_ok;
+    int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
+    int D, NH, n_mt, n_classes, n_heads, out_dim;
+    int head_odim[kMaxHeads];
+    int head_sigmoid[kMaxHeads];
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -43,9 +50,90 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // Packed per-block weights: [conv A: 24 steps x 2 M-tiles x 64 lanes][1x1 A: 8 x 2 x 64][b1 32][b2 32]
 constexpr int kBlockFloats = 24 * 2 * 64 + 8 * 2 * 64 + 32 + 32;
 
-__global__ void __launch_bounds__(256, 2)
-tcn_trunk_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
-                 float *__restrict__ trunk) {
+struct BlockW {
+    float wc[24][2], wp[8][2];
+    f32x4 b1lo, b1hi, b2lo, b2hi;
+};
+
+__device__ __forceinline__ void load_block(BlockW &w, const float *__restrict__ wblk, int lane, int q) {
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+        w.wc[s][0] = wblk[(s * 2 + 0) * 64 + lane];
+        w.wc[s][1] = wblk[(s * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        w.wp[s][0] = wblk[24 * 2 * 64 + (s * 2 + 0) * 64 + lane];
+        w.wp[s][1] = wblk[24 * 2 * 64 + (s * 2 + 1) * 64 + lane];
+    }
+    const float *b1 = wblk + 24 * 2 * 64 + 8 * 2 * 64;
+    w.b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
+    w.b1hi = *reinterpret_cast<const f32x4 *>(b1 + 16 + 4 * q);
+    w.b2lo = *reinterpret_cast<const f32x4 *>(b1 + 32 + 4 * q);
+    w.b2hi = *reinterpret_cast<const f32x4 *>(b1 + 48 + 4 * q);
+}
+
+// one residual block for this wave's column tiles ("units" of 16 time steps)
+__device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR, int units, int wave, int nw, int q,
+                                          int j, const float *__restrict__ xin, float *__restrict__ xout) {
+    const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
+    for (int u = wave; u < units; u += nw) {
+        const int R = 16 * u + j;
+        const int Rc = min(R, GR - 1);
+        const int t = Rc % T;
+        f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
+        // dilated conv: k index = tap*32 + c, step s covers c = (4s % 32) + q of tap s/8
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            if (tap != 1 && !side_taps) continue;
+            const int off = (tap - 1) * d;
+            const bool ok = (t + off >= 0) && (t + off < T);
+            const float *src = xin + (size_t)(ok ? Rc + off : Rc) * SX + q;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                float bv = src[4 * s8];
+                bv = ok ? bv : 0.f;
+                acc0 = mfma4(w.wc[tap * 8 + s8][0], bv, acc0);
+                acc1 = mfma4(w.wc[tap * 8 + s8][1], bv, acc1);
+            }
+        }
+        // relu + channel-max normalisation ('norm_relu')
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0[r] = fmaxf(acc0[r], 0.f);
+            acc1[r] = fmaxf(acc1[r], 0.f);
+            mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float inv = 1.0f / (mx + kNormEps);
+        // 1x1 conv on the normalised activations + bias + residual, all from registers
+        const float *res = xin + (size_t)Rc * SX + 4 * q;
+        f32x4 o0 = *reinterpret_cast<const f32x4 *>(res) + w.b2lo;
+        f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16) + w.b2hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y0 = acc0[r] * inv;  // channel 4q + r
+            o0 = mfma4(w.wp[r][0], y0, o0);
+            o1 = mfma4(w.wp[r][1], y0, o1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y1 = acc1[r] * inv;  // channel 16 + 4q + r
+            o0 = mfma4(w.wp[4 + r][0], y1, o0);
+            o1 = mfma4(w.wp[4 + r][1], y1, o1);
+        }
+        float *dst = xout + (size_t)R * SX + 4 * q;
+        *reinterpret_cast<f32x4 *>(dst) = o0;
+        *reinterpret_cast<f32x4 *>(dst + 16) = o1;
+    }
+}
+
+__global__ void __launch_bounds__(512, 2)
+b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
+                     const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
+                     float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int q = lane >> 4, j = lane & 15;
@@ -54,8 +142,10 @@ tcn_trunk_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict
     const int T = a.T;
     const int GR = g_here * T;
     const int units = (GR + 15) >> 4;
-    const int GRP = ((a.G * T + 15) >> 4) << 4;
-    float *xa = lds, *xb = lds + (size_t)GRP * SX;
+    float *xa = lds, *xb = lds + (size_t)a.GRP * SX;
+
+    BlockW wA, wB;
+    load_block(wA, Wb, lane, q);  // block 0's weights travel while layer 0 computes
 
     // ---- initial Conv1D(32, 1): K order f = q*FQ + s so that every lane streams a contiguous run ----
     {
@@ -91,148 +181,78 @@ tcn_trunk_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict
         }
     }
 
-    // ---- residual blocks ----
+    // ---- residual blocks, two per iteration so that both weight sets have static register names ----
     float *xin = xa, *xout = xb;
-    for (int blk = 0; blk < a.n_blocks; ++blk) {
-        const int d = 1 << (blk % a.n_dil);
-        const float *wblk = Wb + (size_t)blk * kBlockFloats;
-        // A operands of this block in registers (reused by all of this wave's units)
-        float wc[24][2], wp[8][2];
-        const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
-#pragma unroll
-        for (int s = 0; s < 24; ++s) {
-            wc[s][0] = wblk[(s * 2 + 0) * 64 + lane];
-            wc[s][1] = wblk[(s * 2 + 1) * 64 + lane];
+    for (int blk = 0; blk < a.n_blocks; blk += 2) {
+        if (blk + 1 < a.n_blocks) load_block(wB, Wb + (size_t)(blk + 1) * kBlockFloats, lane, q);
+        __syncthreads();  // xin complete
+        run_block(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout);
+        if (blk + 1 < a.n_blocks) {
+            if (blk + 2 < a.n_blocks) load_block(wA, Wb + (size_t)(blk + 2) * kBlockFloats, lane, q);
+            __syncthreads();
+            run_block(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin);
+        } else {
+            float *tmp = xin;
+            xin = xout;
+            xout = tmp;
         }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            wp[s][0] = wblk[24 * 2 * 64 + (s * 2 + 0) * 64 + lane];
-            wp[s][1] = wblk[24 * 2 * 64 + (s * 2 + 1) * 64 + lane];
-        }
-        const float *b1 = wblk + 24 * 2 * 64 + 8 * 2 * 64;
-        const float *b2 = b1 + 32;
-        const f32x4 b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
-        const f32x4 b1hi = *reinterpret_cast<const f32x4 *>(b1 + 16 + 4 * q);
-        const f32x4 b2lo = *reinterpret_cast<const f32x4 *>(b2 + 4 * q);
-        const f32x4 b2hi = *reinterpret_cast<const f32x4 *>(b2 + 16 + 4 * q);
-        __syncthreads();  // xin complete (written by the previous stage)
-
-        for (int u = wave; u < units; u += nw) {
-            const int R = 16 * u + j;
-            const int Rc = min(R, GR - 1);
-            const int t = Rc % T;
-            f32x4 acc0 = b1lo, acc1 = b1hi;
-            // dilated conv: k index = tap*32 + c, step s covers c = (4s % 32) + q of tap s/8
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                if (tap != 1 && !side_taps) continue;
-                const int off = (tap - 1) * d;
-                const bool ok = (t + off >= 0) && (t + off < T);
-                const float *src = xin + (size_t)(ok ? Rc + off : Rc) * SX + q;
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    float bv = src[4 * s8];
-                    bv = ok ? bv : 0.f;
-                    acc0 = mfma4(wc[tap * 8 + s8][0], bv, acc0);
-                    acc1 = mfma4(wc[tap * 8 + s8][1], bv, acc1);
-                }
-            }
-            // relu + channel-max normalisation ('norm_relu')
-            float mx = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc0[r] = fmaxf(acc0[r], 0.f);
-                acc1[r] = fmaxf(acc1[r], 0.f);
-                mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float inv = 1.0f / (mx + kNormEps);
-            // 1x1 conv on the normalised activations + bias + residual, all from registers
-            const float *res = xin + (size_t)Rc * SX + 4 * q;
-            f32x4 o0 = *reinterpret_cast<const f32x4 *>(res) + b2lo;
-            f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16) + b2hi;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y0 = acc0[r] * inv;  // channel 4q + r
-                o0 = mfma4(wp[r][0], y0, o0);
-                o1 = mfma4(wp[r][1], y0, o1);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y1 = acc1[r] * inv;  // channel 16 + 4q + r
-                o0 = mfma4(wp[4 + r][0], y1, o0);
-                o1 = mfma4(wp[4 + r][1], y1, o1);
-            }
-            float *dst = xout + (size_t)R * SX + 4 * q;
-            *reinterpret_cast<f32x4 *>(dst) = o0;
-            *reinterpret_cast<f32x4 *>(dst + 16) = o1;
-        }
-        float *tmp = xin;
-        xin = xout;
-        xout = tmp;
     }
     __syncthreads();
-    // final relu; trunk (N, T, 32) row-major == Keras Flatten order
-    float *out = trunk + (size_t)n0 * T * C;
+    // final relu in place (xin = TCN output); optional tap to global as (N, T, 32) == Keras Flatten order
     for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
         const int R = i >> 3, c4 = (i & 7) * 4;
         f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (size_t)R * SX + c4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *reinterpret_cast<f32x4 *>(out + (size_t)R * C + c4) = v;
+        *reinterpret_cast<f32x4 *>(xin + (size_t)R * SX + c4) = v;
+        if (trunk) *reinterpret_cast<f32x4 *>(trunk + ((size_t)n0 * T + R) * C + c4) = v;
     }
-}
-
-struct HeadArgs {
-    int N, D, NH, n_classes, n_heads, out_dim;
-    int head_odim[kMaxHeads];
-    int head_sigmoid[kMaxHeads];
-};
-
-// Heads: one workgroup per kHeadPatches patches.  Stage 1: all Dense layers that read the flattened
-// trunk as one (D x NH) product (NH = n_classes + 16*n_heads); stage 2: BN/relu/out-Dense/activations.
-// Packed head params after Wh (D*NH) and bh (NH): per head [gamma16 beta16 mean16 var16 Wout(16*odim) bout(odim)].
-__global__ void __launch_bounds__(256)
-heads_kernel(HeadArgs a, const float *__restrict__ trunk, const float *__restrict__ Wh, const float *__restrict__ hp,
-             float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *flat = sm;                                   // kHeadPatches * D
-    float *part = sm + (size_t)kHeadPatches * a.D;      // parts * NH * kHeadPatches
-    float *pre = part + (size_t)256 * kHeadPatches;     // NH * kHeadPatches
-    const int n0 = blockIdx.x * kHeadPatches;
-    const int np = min(kHeadPatches, a.N - n0);
-    for (int i = threadIdx.x; i < np * a.D; i += blockDim.x) flat[i] = trunk[(size_t)n0 * a.D + i];
-    for (int i = np * a.D + threadIdx.x; i < kHeadPatches * a.D; i += blockDim.x) flat[i] = 0.f;
     __syncthreads();
-    const int parts = 256 / a.NH;
-    const int o = threadIdx.x % a.NH, pt = threadIdx.x / a.NH;
-    if (pt < parts) {
-        const int chunk = (a.D + parts - 1) / parts;
-        const int i0 = pt * chunk, i1 = min(a.D, i0 + chunk);
-        float acc[kHeadPatches];
+
+    // ---- Dense layers on the flattened trunk: D[o][g] = sum_k WhT[o][k] * flat[g][k], k = t*32 + c ----
+    // A (weights) pre-packed per M-tile as [k/16][lane][4]: one 16-byte load feeds four MFMA steps.
+    // Waves beyond the number of M-tiles split the k range (partial sums are added in the epilogue).
+    float *pre = xout;  // scratch [nks][kMaxG][64]: the other activation buffer is free now
+    const int steps4 = a.D / 16;
+    const int nks = max(1, nw / a.n_mt);
+    {
+        const int mt = wave % a.n_mt, ks = wave / a.n_mt;
+        if (ks < nks) {
+            const int s_lo = (int)((long)steps4 * ks / nks), s_hi = (int)((long)steps4 * (ks + 1) / nks);
+            const f32x4 *wa = reinterpret_cast<const f32x4 *>(WhA) + (size_t)mt * steps4 * 64 + lane;
+            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+            const bool live = j < g_here;
+            const float *xg = xin + (size_t)(live ? j : 0) * T * SX + q;
+#pragma unroll 4
+            for (int s4 = s_lo; s4 < s_hi; ++s4) {
+                const f32x4 wv = wa[(size_t)s4 * 64];
+                // k = 16*s4 + 4*e + q  ->  t = s4 / 2, c = 16*(s4 & 1) + 4*e + q
+                const float *xr = xg + (size_t)(s4 >> 1) * SX + 16 * (s4 & 1);
+                float b0 = xr[0], b1 = xr[4], b2 = xr[8], b3 = xr[12];
+                if (!live) b0 = b1 = b2 = b3 = 0.f;
+                accA = mfma4(wv[0], b0, accA);
+                accB = mfma4(wv[1], b1, accB);
+                accA = mfma4(wv[2], b2, accA);
+                accB = mfma4(wv[3], b3, accB);
+            }
+            accA += accB;
 #pragma unroll
-        for (int p = 0; p < kHeadPatches; ++p) acc[p] = 0.f;
-        for (int i = i0; i < i1; ++i) {
-            const float w = Wh[(size_t)i * a.NH + o];
-#pragma unroll
-            for (int p = 0; p < kHeadPatches; ++p) acc[p] = fmaf(flat[p * a.D + i], w, acc[p]);
+            for (int r = 0; r < 4; ++r) pre[(ks * kMaxG + j) * 64 + 16 * mt + 4 * q + r] = accA[r];
         }
-#pragma unroll
-        for (int p = 0; p < kHeadPatches; ++p) part[(pt * a.NH + o) * kHeadPatches + p] = acc[p];
     }
     __syncthreads();
-    const float *bh = Wh + (size_t)a.D * a.NH;
-    for (int i = threadIdx.x; i < a.NH * kHeadPatches; i += blockDim.x) {
-        const int oo = i / kHeadPatches, p = i - oo * kHeadPatches;
-        float s = bh[oo];
-        for (int k = 0; k < parts; ++k) s += part[(k * a.NH + oo) * kHeadPatches + p];
-        pre[oo * kHeadPatches + p] = s;
+    if (nks > 1) {
+        for (int i = threadIdx.x; i < kMaxG * 64; i += blockDim.x) {
+            float v = pre[i];
+            for (int k2 = 1; k2 < nks; ++k2) v += pre[k2 * kMaxG * 64 + i];
+            pre[i] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // stage 2: one thread per (patch, head) and one per patch for the softmax
+    // ---- BN / relu / output Dense / activations: one thread per (patch, head), one per patch for 3C ----
+    const float *bh = WhA + (size_t)a.n_mt * steps4 * 64 * 4;  // NH biases follow the packed weights
     const int tid = threadIdx.x;
-    if (tid < np * a.n_heads) {
+    if (tid < g_here * a.n_heads) {
         const int p = tid / a.n_heads, h = tid - p * a.n_heads;
         const float *ph = hp;
         int col = 0;
@@ -246,7 +266,8 @@ heads_kernel(HeadArgs a, const float *__restrict__ trunk, const float *__restric
         float hid[kHidden];
 #pragma unroll
         for (int i = 0; i < kHidden; ++i) {
-            float v = pre[(a.n_classes + h * kHidden + i) * kHeadPatches + p];
+            const int o = a.n_classes + h * kHidden + i;
+            float v = pre[p * 64 + o] + bh[o];
             v = (v - mean[i]) / sqrtf(var[i] + kBnEps);
             v = v * gamma[i] + beta[i];
             hid[i] = fmaxf(v, 0.f);
@@ -258,15 +279,15 @@ heads_kernel(HeadArgs a, const float *__restrict__ trunk, const float *__restric
             if (a.head_sigmoid[h]) s = 1.0f / (1.0f + expf(-s));
             out[(size_t)(n0 + p) * a.out_dim + col + c] = s;
         }
-    } else if (tid >= 128 && tid < 128 + np) {
+    } else if (tid >= 128 && tid < 128 + g_here) {
         const int p = tid - 128;
         float mxl = -INFINITY;
-        for (int c = 0; c < a.n_classes; ++c) mxl = fmaxf(mxl, pre[c * kHeadPatches + p]);
+        for (int c = 0; c < a.n_classes; ++c) mxl = fmaxf(mxl, pre[p * 64 + c] + bh[c]);
         float den = 0.f;
-        for (int c = 0; c < a.n_classes; ++c) den += expf(pre[c * kHeadPatches + p] - mxl);
+        for (int c = 0; c < a.n_classes; ++c) den += expf(pre[p * 64 + c] + bh[c] - mxl);
         const int col = a.out_dim - a.n_classes;
         for (int c = 0; c < a.n_classes; ++c)
-            out[(size_t)(n0 + p) * a.out_dim + col + c] = expf(pre[c * kHeadPatches + p] - mxl) / den;
+            out[(size_t)(n0 + p) * a.out_dim + col + c] = expf(pre[p * 64 + c] + bh[c] - mxl) / den;
     }
 }
 
@@ -274,16 +295,14 @@ heads_kernel(HeadArgs a, const float *__restrict__ trunk, const float *__restric
 
 struct smh_model {
     smh_model_cfg cfg;
-    int n_blocks, n_heads, NH, D, out_dim, FQ;
+    int n_blocks, n_heads, NH, n_mt, D, out_dim, FQ;
     int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
     size_t n_params;
-    float *d_W0 = nullptr;     // layer-0 A operands + bias0
-    float *d_Wb = nullptr;     // per-block packed weights
-    float *d_Wh = nullptr;     // (D x NH) + bh
-    float *d_hp = nullptr;     // per-head BN / out params
-    float *d_trunk = nullptr;  // scratch when the caller passes no tap
-    size_t trunk_cap = 0;
-    size_t nW0, nWb, nWh, nhp;
+    float *d_W0 = nullptr;   // layer-0 A operands + bias0
+    float *d_Wb = nullptr;   // per-block packed weights
+    float *d_WhA = nullptr;  // Dense-on-trunk weights in A-operand order + biases
+    float *d_hp = nullptr;   // per-head BN / out params
+    size_t nW0, nWb, nWhA, nhp;
 };
 
 extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
@@ -308,10 +327,10 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     }
     m->D = cfg->patch_size * C;
     m->NH = cfg->n_classes + kHidden * m->n_heads;
+    m->n_mt = (m->NH + 15) / 16;
     m->out_dim = cfg->n_classes;
     for (int i = 0; i < m->n_heads; ++i) m->out_dim += m->head_odim[i];
     m->FQ = (cfg->n_feat + 3) / 4;
-    if ((cfg->n_feat % 4 == 0) && (m->FQ % 4 != 0)) { /* contiguous runs still fine, float4 path needs FQ%4==0 */ }
     size_t n = (size_t)cfg->n_feat * C + C;
     n += (size_t)m->n_blocks * (3 * C * C + C + C * C + C);
     n += (size_t)m->D * cfg->n_classes + cfg->n_classes;
@@ -320,12 +339,12 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     m->n_params = n;
     m->nW0 = (size_t)m->FQ * 2 * 64 + 32;
     m->nWb = (size_t)m->n_blocks * kBlockFloats;
-    m->nWh = (size_t)m->D * m->NH + m->NH;
+    m->nWhA = (size_t)m->n_mt * (m->D / 16) * 64 * 4 + (size_t)m->n_mt * 16;
     m->nhp = 0;
     for (int i = 0; i < m->n_heads; ++i) m->nhp += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
     hipError_t e = hipMalloc((void **)&m->d_W0, m->nW0 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Wb, m->nWb * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Wh, m->nWh * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_WhA, m->nWhA * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_hp, m->nhp * sizeof(float));
     if (e != hipSuccess) {
         smh_model_destroy(m);
@@ -339,9 +358,8 @@ extern "C" void smh_model_destroy(smh_model *m) {
     if (!m) return;
     (void)hipFree(m->d_W0);
     (void)hipFree(m->d_Wb);
-    (void)hipFree(m->d_Wh);
+    (void)hipFree(m->d_WhA);
     (void)hipFree(m->d_hp);
-    (void)hipFree(m->d_trunk);
     delete m;
 }
 
@@ -356,7 +374,8 @@ extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, voi
     SMH_REQUIRE(m && h, "smh_model_set_weights: null argument");
     SMH_REQUIRE(n == m->n_params, "smh_model_set_weights: got %zu floats, model has %zu", n, m->n_params);
     const int F = m->cfg.n_feat, FQ = m->FQ, D = m->D, NH = m->NH, ncls = m->cfg.n_classes;
-    std::vector<float> W0(m->nW0, 0.f), Wb(m->nWb, 0.f), Wh(m->nWh, 0.f), hp(m->nhp, 0.f);
+    std::vector<float> W0(m->nW0, 0.f), Wb(m->nWb, 0.f), WhA(m->nWhA, 0.f), hp(m->nhp, 0.f);
+    std::vector<float> Wh((size_t)D * NH, 0.f), bhv((size_t)m->n_mt * 16, 0.f);
     const float *p = h;
     // layer 0: A[s][m'][lane] = W0[f = q*FQ + s][16m' + i]
     for (int s = 0; s < FQ; ++s)
@@ -395,14 +414,14 @@ extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, voi
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64, b1, C * sizeof(float));
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64 + 32, b2, C * sizeof(float));
     }
-    // heads: column order [3C | head0 dense16 | head1 dense16 | ...]
+    // Dense-on-trunk matrix, column order [3C | head0 dense16 | head1 dense16 | ...]
     const float *k3c = p;
     p += (size_t)D * ncls;
     const float *b3c = p;
     p += ncls;
     for (int i = 0; i < D; ++i)
         for (int c = 0; c < ncls; ++c) Wh[(size_t)i * NH + c] = k3c[(size_t)i * ncls + c];
-    for (int c = 0; c < ncls; ++c) Wh[(size_t)D * NH + c] = b3c[c];
+    for (int c = 0; c < ncls; ++c) bhv[c] = b3c[c];
     float *php = hp.data();
     for (int hd = 0; hd < m->n_heads; ++hd) {
         const float *kd = p;
@@ -411,68 +430,62 @@ extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, voi
         p += kHidden;
         for (int i = 0; i < D; ++i)
             for (int c = 0; c < kHidden; ++c) Wh[(size_t)i * NH + ncls + hd * kHidden + c] = kd[(size_t)i * kHidden + c];
-        for (int c = 0; c < kHidden; ++c) Wh[(size_t)D * NH + ncls + hd * kHidden + c] = bd[c];
+        for (int c = 0; c < kHidden; ++c) bhv[ncls + hd * kHidden + c] = bd[c];
         const int od = m->head_odim[hd];
         const size_t cnt = 4 * kHidden + (size_t)kHidden * od + od;
         std::memcpy(php, p, cnt * sizeof(float));  // gamma beta mean var Wout bout are contiguous in canonical order
         php += cnt;
         p += cnt;
     }
+    // A-operand packing: WhA[mt][s4][lane][e] = Wh[k = 16*s4 + 4*e + q][o = 16*mt + i]   (0 for o >= NH)
+    const int steps4 = D / 16;
+    for (int mt = 0; mt < m->n_mt; ++mt)
+        for (int s4 = 0; s4 < steps4; ++s4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int q = lane >> 4, i = lane & 15, k = 16 * s4 + 4 * e + q, o = 16 * mt + i;
+                    WhA[(((size_t)mt * steps4 + s4) * 64 + lane) * 4 + e] = o < NH ? Wh[(size_t)k * NH + o] : 0.f;
+                }
+    std::memcpy(&WhA[(size_t)m->n_mt * steps4 * 64 * 4], bhv.data(), bhv.size() * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     SMH_CHECK_HIP(hipMemcpyAsync(m->d_W0, W0.data(), W0.size() * sizeof(float), hipMemcpyHostToDevice, st));
     SMH_CHECK_HIP(hipMemcpyAsync(m->d_Wb, Wb.data(), Wb.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    SMH_CHECK_HIP(hipMemcpyAsync(m->d_Wh, Wh.data(), Wh.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    SMH_CHECK_HIP(hipMemcpyAsync(m->d_WhA, WhA.data(), WhA.size() * sizeof(float), hipMemcpyHostToDevice, st));
     SMH_CHECK_HIP(hipMemcpyAsync(m->d_hp, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice, st));
     SMH_CHECK_HIP(hipStreamSynchronize(st));  // the staging vectors die here
     return SMH_OK;
 }
 
-extern "C" int smh_model_forward_f32(const smh_model *mc, const float *d_x, int N, float *d_out, float *d_trunk,
+extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk,
                                      void *stream) {
-    smh_model *m = const_cast<smh_model *>(mc);
     SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_f32: null argument");
     SMH_REQUIRE(N >= 0, "smh_model_forward_f32: N=%d", N);
     if (N == 0) return SMH_OK;
-    hipStream_t st = (hipStream_t)stream;
     const int T = m->cfg.patch_size;
-    float *trunk = d_trunk;
-    if (!trunk) {
-        const size_t need = (size_t)N * T * C;
-        if (need > m->trunk_cap) {
-            // grows outside any stream capture: callers that capture graphs pass d_trunk or warm up first
-            (void)hipFree(m->d_trunk);
-            m->d_trunk = nullptr, m->trunk_cap = 0;
-            SMH_CHECK_HIP(hipMalloc((void **)&m->d_trunk, need * sizeof(float)));
-            m->trunk_cap = need;
-        }
-        trunk = m->d_trunk;
-    }
     TcnArgs a;
     a.N = N, a.T = T, a.F = m->cfg.n_feat, a.FQ = m->FQ, a.n_blocks = m->n_blocks, a.n_dil = m->cfg.n_dilations;
     a.vec_ok = (a.F % 4 == 0) && (a.FQ % 4 == 0) && (a.FQ * 4 == a.F);
-    // patches per workgroup: up to 272 rows (17 column tiles) of LDS-resident activations, but never
-    // fewer workgroups than CUs when the batch allows it
+    a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
+    a.out_dim = m->out_dim;
+    for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
+    // patches per workgroup: up to 272 rows (17 column tiles) of LDS-resident activations, at most one
+    // MFMA tile of patches, and never fewer workgroups than CUs when the batch allows it
     int gmax = 272 / T;
     if (gmax < 1) gmax = 1;
+    if (gmax > kMaxG) gmax = kMaxG;
     int G = N / 256;
     if (G < 1) G = 1;
     if (G > gmax) G = gmax;
     a.G = G;
-    const int GRP = ((G * T + 15) / 16) * 16;
+    int GRP = ((G * T + 15) / 16) * 16;
+    if (GRP * SX < 8 * kMaxG * 64) GRP = (8 * kMaxG * 64 + SX - 1) / SX;  // the head scratch lives in one buffer
+    GRP = ((GRP + 15) / 16) * 16;
+    a.GRP = GRP;
     const size_t lds = sizeof(float) * 2 * (size_t)GRP * SX;
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", T);
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tcn_trunk_kernel, dim3((N + G - 1) / G), dim3(256), lds, st, a, d_x, m->d_W0, m->d_Wb, trunk);
-    int rc = smh::launch_status("tcn_trunk_kernel");
-    if (rc) return rc;
-
-    HeadArgs ha;
-    ha.N = N, ha.D = m->D, ha.NH = m->NH, ha.n_classes = m->cfg.n_classes, ha.n_heads = m->n_heads, ha.out_dim = m->out_dim;
-    for (int i = 0; i < kMaxHeads; ++i) ha.head_odim[i] = m->head_odim[i], ha.head_sigmoid[i] = m->head_sigmoid[i];
-    const size_t hl = sizeof(float) * ((size_t)kHeadPatches * m->D + 256 * kHeadPatches + (size_t)m->NH * kHeadPatches);
-    SMH_REQUIRE(hl <= 156 * 1024, "patch_size %d too long for the heads kernel", T);
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-    hipLaunchKernelGGL(heads_kernel, dim3((N + kHeadPatches - 1) / kHeadPatches), dim3(256), hl, st, ha, trunk, m->d_Wh,
-                       m->d_hp, d_out);
-    return smh::launch_status("heads_kernel");
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    hipLaunchKernelGGL(b3mtl_forward_kernel, dim3((N + G - 1) / G), dim3(512), lds, (hipStream_t)stream, a, d_x, m->d_W0,
+                       m->d_Wb, m->d_WhA, m->d_hp, d_trunk, d_out);
+    return smh::launch_status("b3mtl_forward_kernel");
 }
