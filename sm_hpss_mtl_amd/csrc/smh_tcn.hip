@@ -19,6 +19,7 @@
 // same kernel as one more MFMA product D[output][patch] on the LDS-resident activations; BN / relu /
 // output Dense / sigmoid / softmax finish in a few threads.  One launch per forward.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,7 +39,7 @@ constexpr float kBnEps = 1e-3f;
 
 struct TcnArgs {
     int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
-    int D, NH, n_mt, n_classes, n_heads, out_dim;
+    int D, NH, n_mt, n_classes, n_heads, out_dim, skip_heads;
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];
 };
@@ -144,42 +145,70 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     const int units = (GR + 15) >> 4;
     float *xa = lds, *xb = lds + (size_t)a.GRP * SX;
 
-    BlockW wA, wB;
-    load_block(wA, Wb, lane, q);  // block 0's weights travel while layer 0 computes
-
     // ---- initial Conv1D(32, 1): K order f = q*FQ + s so that every lane streams a contiguous run ----
+    // Layer 0 is an HBM stream (261 KB of X per workgroup): every lane issues ALL loads of its column
+    // tiles first (registers are free: the block weights are not loaded yet), so one HBM latency is
+    // exposed instead of one per k-group.  A operands are staged once in LDS and shared by all tiles.
+    constexpr int kMaxU = 3;    // column tiles per wave (17 tiles over 8 waves)
+    constexpr int kFQ4 = 15;    // float4 groups per lane for n_feat = 240
     {
-        const float *bias0 = W0 + (size_t)a.FQ * 2 * 64;
-        for (int u = wave; u < units; u += nw) {
-            const int R = 16 * u + j;
-            const int Rc = min(R, GR - 1);
-            const float *xrow = X + ((size_t)n0 * T + Rc) * a.F + (size_t)q * a.FQ;
-            f32x4 acc0 = *reinterpret_cast<const f32x4 *>(bias0 + 4 * q);
-            f32x4 acc1 = *reinterpret_cast<const f32x4 *>(bias0 + 16 + 4 * q);
-            const float *wa = W0 + lane;
-            if (a.vec_ok) {
-                for (int s = 0; s < a.FQ; s += 4) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + s);
+        float *w0s = xb;  // layer-0 A operands live in the not-yet-used activation buffer
+        const int nW0 = a.FQ * 2 * 64;
+        const float *bias0 = W0 + (size_t)nW0;
+        const f32x4 bl = *reinterpret_cast<const f32x4 *>(bias0 + 4 * q);
+        const f32x4 bh = *reinterpret_cast<const f32x4 *>(bias0 + 16 + 4 * q);
+        if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kMaxU * nw) {
+            f32x4 xr[kMaxU][kFQ4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a0 = wa[(size_t)((s + e) * 2 + 0) * 64];
-                        const float a1 = wa[(size_t)((s + e) * 2 + 1) * 64];
-                        acc0 = mfma4(a0, xv[e], acc0);
-                        acc1 = mfma4(a1, xv[e], acc1);
+            for (int i = 0; i < kMaxU; ++i) {
+                const int u = min(wave + i * nw, units - 1);
+                const int Rc = min(16 * u + j, GR - 1);
+                const float *xrow = X + ((size_t)n0 * T + Rc) * a.F + (size_t)q * a.FQ;
+#pragma unroll
+                for (int g = 0; g < kFQ4; ++g) xr[i][g] = *reinterpret_cast<const f32x4 *>(xrow + 4 * g);
+            }
+            for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = W0[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kMaxU; ++i) {
+                const int u = wave + i * nw;
+                if (u < units) {  // wave-uniform
+                    f32x4 c0 = bl, c1 = bh;
+#pragma unroll
+                    for (int g = 0; g < kFQ4; ++g) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            c0 = mfma4(w0s[((4 * g + e) * 2 + 0) * 64 + lane], xr[i][g][e], c0);
+                            c1 = mfma4(w0s[((4 * g + e) * 2 + 1) * 64 + lane], xr[i][g][e], c1);
+                        }
                     }
-                }
-            } else {
-                for (int s = 0; s < a.FQ; ++s) {
-                    const float xv = (q * a.FQ + s < a.F) ? xrow[s] : 0.f;
-                    acc0 = mfma4(wa[(size_t)(s * 2 + 0) * 64], xv, acc0);
-                    acc1 = mfma4(wa[(size_t)(s * 2 + 1) * 64], xv, acc1);
+                    float *dst = xa + (size_t)(16 * u + j) * SX + 4 * q;
+                    *reinterpret_cast<f32x4 *>(dst) = c0;
+                    *reinterpret_cast<f32x4 *>(dst + 16) = c1;
                 }
             }
-            float *dst = xa + (size_t)R * SX + 4 * q;
-            *reinterpret_cast<f32x4 *>(dst) = acc0;
-            *reinterpret_cast<f32x4 *>(dst + 16) = acc1;
+        } else {
+            for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = W0[i];
+            __syncthreads();
+            for (int u = wave; u < units; u += nw) {
+                const int R = 16 * u + j;
+                const int Rc = min(R, GR - 1);
+                const float *xr = X + ((size_t)n0 * T + Rc) * a.F + (size_t)q * a.FQ;
+                f32x4 c0 = bl, c1 = bh;
+                for (int s = 0; s < a.FQ; ++s) {
+                    const float xv = (q * a.FQ + s < a.F) ? xr[s] : 0.f;
+                    c0 = mfma4(w0s[(s * 2 + 0) * 64 + lane], xv, c0);
+                    c1 = mfma4(w0s[(s * 2 + 1) * 64 + lane], xv, c1);
+                }
+                float *dst = xa + (size_t)R * SX + 4 * q;
+                *reinterpret_cast<f32x4 *>(dst) = c0;
+                *reinterpret_cast<f32x4 *>(dst + 16) = c1;
+            }
         }
     }
+
+    BlockW wA, wB;
+    load_block(wA, Wb, lane, q);
 
     // ---- residual blocks, two per iteration so that both weight sets have static register names ----
     float *xin = xa, *xout = xb;
@@ -217,13 +246,13 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     const int nks = max(1, nw / a.n_mt);
     {
         const int mt = wave % a.n_mt, ks = wave / a.n_mt;
-        if (ks < nks) {
+        if (ks < nks && !a.skip_heads) {
             const int s_lo = (int)((long)steps4 * ks / nks), s_hi = (int)((long)steps4 * (ks + 1) / nks);
             const f32x4 *wa = reinterpret_cast<const f32x4 *>(WhA) + (size_t)mt * steps4 * 64 + lane;
             f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
             const bool live = j < g_here;
             const float *xg = xin + (size_t)(live ? j : 0) * T * SX + q;
-#pragma unroll 4
+#pragma unroll 8
             for (int s4 = s_lo; s4 < s_hi; ++s4) {
                 const f32x4 wv = wa[(size_t)s4 * 64];
                 // k = 16*s4 + 4*e + q  ->  t = s4 / 2, c = 16*(s4 & 1) + 4*e + q
@@ -465,6 +494,8 @@ extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N
     TcnArgs a;
     a.N = N, a.T = T, a.F = m->cfg.n_feat, a.FQ = m->FQ, a.n_blocks = m->n_blocks, a.n_dil = m->cfg.n_dilations;
     a.vec_ok = (a.F % 4 == 0) && (a.FQ % 4 == 0) && (a.FQ * 4 == a.F);
+    if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
+    a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
     for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
@@ -479,6 +510,7 @@ extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N
     a.G = G;
     int GRP = ((G * T + 15) / 16) * 16;
     if (GRP * SX < 8 * kMaxG * 64) GRP = (8 * kMaxG * 64 + SX - 1) / SX;  // the head scratch lives in one buffer
+    if (GRP * SX < m->FQ * 2 * 64) GRP = (m->FQ * 2 * 64 + SX - 1) / SX;  // layer-0 A operands are staged there
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
     const size_t lds = sizeof(float) * 2 * (size_t)GRP * SX;
