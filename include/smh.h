@@ -159,6 +159,31 @@ int smh_model_out_dim(const smh_model *m);
  * (Proposed_Work_Results.py:520,586).  d_trunk (N, W, nb_filters) optional TCN output tap.      */
 int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
 
+/* download the (device-resident, possibly trained) weights in canonical order */
+int smh_model_get_weights(const smh_model *m, float *h_flat, size_t n, void *stream);
+
+/* ---- a14: one training step = what model.fit runs per batch (Proposed_Work_Results.py:298-307) for the
+ * model compiled at lib/proposed_architectures.py:156-165: BCE (S, M[, N]) + MSE (R) + CCE (3C) with optional
+ * loss_weights, l2(0.01) on the Dense(16) kernels, SGD(momentum, clipnorm, lr from ExponentialDecay).
+ * The trainer owns activations, gradients (canonical order) and momentum; weights stay on the device.  */
+typedef struct smh_trainer smh_trainer;
+int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out);
+void smh_trainer_destroy(smh_trainer *t);
+/* device pointer to the flat gradient (smh_model_num_params floats, canonical order): all-reduce it over
+ * RCCL between smh_train_step_f32 and smh_trainer_apply_sgd_f32 for data-parallel training. */
+float *smh_trainer_grad_ptr(smh_trainer *t);
+/* forward (training mode) + losses + backward for one batch.
+ *   d_x (N, W, n_feat); d_y (N, out_dim) targets laid out like the forward output [S | M | (N) | R | 3C one-hot]
+ *   d_drop_tcn  (N, n_blocks, 32) SpatialDropout1D masks (0 or 1/(1-rate)) or NULL (no dropout)
+ *   d_drop_heads (N, n_heads, 16) Dropout(0.4) masks (0 or 1/0.6) or NULL
+ *   h_loss_weights: n_heads + 1 host floats in output order (NULL = all 1)
+ *   d_losses: n_heads + 3 floats out = [per-head losses..., 3C loss, weighted sum (without the l2 term), 3C accuracy] */
+int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
+                       const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream);
+/* g = grad * grad_scale (+ l2 term); per-tensor clip to `clipnorm` (<= 0: off); v = momentum*v - lr*g; w += v;
+ * BN moving statistics <- 0.99*old + 0.01*batch; operand buffers re-packed on the device.              */
+int smh_trainer_apply_sgd_f32(smh_trainer *t, float lr, float momentum, float clipnorm, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,12 @@ SIGNATURES = {
     "smh_model_set_weights": (_i, [_vp, _vp, _sz, _vp]),
     "smh_model_out_dim": (_i, [_vp]),
     "smh_model_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
+    "smh_model_get_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "smh_trainer_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "smh_trainer_destroy": (None, [_vp]),
+    "smh_trainer_grad_ptr": (_vp, [_vp]),
+    "smh_train_step_f32": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp, _fp, _vp]),
+    "smh_trainer_apply_sgd_f32": (_i, [_vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,64 @@
+// Internal definition of the B3_MTL model object shared by the inference (smh_tcn.hip) and training
+// (smh_train.hip) translation units.
+#pragma once
+#include "smh_common.h"
+
+namespace smh_tcn {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int C = 32;          // nb_filters (fixed by the MFMA tiling)
+constexpr int SX = 36;         // LDS row stride of x in floats (16-byte aligned rows)
+constexpr int kMaxHeads = 4;
+constexpr int kHidden = 16;    // Dense(16) of every MTL head
+constexpr int kMaxG = 16;      // patches per workgroup <= MFMA N
+constexpr int kPS = 80;        // row stride of the Dense-on-trunk outputs: up to 5 M-tiles (5-class: 69 outputs)
+constexpr float kNormEps = 1e-5f;
+constexpr float kBnEps = 1e-3f;
+// Packed per-block weights: [conv A: 24 steps x 2 M-tiles x 64 lanes][1x1 A: 8 x 2 x 64][b1 32][b2 32]
+constexpr int kBlockFloats = 24 * 2 * 64 + 8 * 2 * 64 + 32 + 32;
+
+struct TcnArgs {
+    int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
+    int D, NH, n_mt, n_classes, n_heads, out_dim, skip_heads;
+    int head_odim[kMaxHeads];
+    int head_sigmoid[kMaxHeads];
+};
+
+// training-mode extras of the forward kernel (all optional)
+struct TrainIO {
+    float *acts;            // (N, n_blocks + 1, T, 32): input of every block, then the pre-relu TCN output
+    const float *drop_tcn;  // (N, n_blocks, 32) SpatialDropout1D masks (0 or 1/(1-rate)), or nullptr
+    float *pre;             // (N, kPS): Dense-on-trunk outputs incl. bias (3C logits | head Dense(16)s)
+};
+
+}  // namespace smh_tcn
+
+struct smh_model {
+    smh_model_cfg cfg;
+    int n_blocks, n_heads, NH, n_mt, D, out_dim, FQ;
+    int head_odim[smh_tcn::kMaxHeads], head_sigmoid[smh_tcn::kMaxHeads];
+    size_t n_params;
+    float *d_flat = nullptr;  // master weights, canonical (Keras-layout) order, n_params floats
+    float *d_W0 = nullptr;    // layer-0 A operands + bias0
+    float *d_Wb = nullptr;    // per-block packed weights
+    float *d_WhA = nullptr;   // Dense-on-trunk weights in A-operand order + biases
+    float *d_hp = nullptr;    // per-head BN / out params
+    int *d_map = nullptr;     // gather map: packed[i] = map[i] ? flat[map[i]-1] : 0 for [W0 | Wb | WhA | hp]
+    size_t nW0, nWb, nWhA, nhp;
+};
+
+namespace smh_tcn {
+// canonical offsets
+struct Offsets {
+    size_t w0_k, w0_b;                 // initial conv kernel / bias
+    size_t blk0, blk_stride;           // first block; per block: k1 (3*C*C), b1 (C), k2 (C*C), b2 (C)
+    size_t c3_k, c3_b;                 // 3C kernel (D x ncls), bias
+    size_t head[kMaxHeads];            // per head: dense k (D x 16), dense b, gamma, beta, mean, var, out k, out b
+};
+Offsets offsets(const smh_model *m);
+void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
+int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
+int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
+                   hipStream_t st);
+}  // namespace smh_tcn

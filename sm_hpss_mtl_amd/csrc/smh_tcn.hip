@@ -23,33 +23,15 @@
 #include <cstring>
 #include <vector>
 
-#include "smh_common.h"
+#include "smh_model.h"
+
+using namespace smh_tcn;
 
 namespace {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int C = 32;          // nb_filters (fixed by the MFMA tiling)
-constexpr int SX = 36;         // LDS row stride of x in floats (16-byte aligned rows)
-constexpr int kMaxHeads = 4;
-constexpr int kHidden = 16;    // Dense(16) of every MTL head
-constexpr int kMaxG = 16;      // patches per workgroup <= MFMA N
-constexpr float kNormEps = 1e-5f;
-constexpr float kBnEps = 1e-3f;
-
-struct TcnArgs {
-    int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
-    int D, NH, n_mt, n_classes, n_heads, out_dim, skip_heads;
-    int head_odim[kMaxHeads];
-    int head_sigmoid[kMaxHeads];
-};
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-
-// Packed per-block weights: [conv A: 24 steps x 2 M-tiles x 64 lanes][1x1 A: 8 x 2 x 64][b1 32][b2 32]
-constexpr int kBlockFloats = 24 * 2 * 64 + 8 * 2 * 64 + 32 + 32;
 
 struct BlockW {
     float wc[24][2], wp[8][2];
@@ -75,8 +57,11 @@ __device__ __forceinline__ void load_block(BlockW &w, const float *__restrict__ 
 }
 
 // one residual block for this wave's column tiles ("units" of 16 time steps)
+// drop: SpatialDropout1D masks of this block for the workgroup's first patch, (n, blk) stride dstride
+template <bool TRAIN>
 __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR, int units, int wave, int nw, int q,
-                                          int j, const float *__restrict__ xin, float *__restrict__ xout) {
+                                          int j, const float *__restrict__ xin, float *__restrict__ xout,
+                                          const float *__restrict__ drop, int dstride) {
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
     for (int u = wave; u < units; u += nw) {
         const int R = 16 * u + j;
@@ -109,19 +94,27 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float inv = 1.0f / (mx + kNormEps);
+        f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (TRAIN) {
+            if (drop) {
+                const float *dp = drop + (size_t)(Rc / T) * dstride + 4 * q;
+                dm0 = *reinterpret_cast<const f32x4 *>(dp);
+                dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
+            }
+        }
         // 1x1 conv on the normalised activations + bias + residual, all from registers
         const float *res = xin + (size_t)Rc * SX + 4 * q;
         f32x4 o0 = *reinterpret_cast<const f32x4 *>(res) + w.b2lo;
         f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16) + w.b2hi;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float y0 = acc0[r] * inv;  // channel 4q + r
+            const float y0 = acc0[r] * inv * dm0[r];  // channel 4q + r
             o0 = mfma4(w.wp[r][0], y0, o0);
             o1 = mfma4(w.wp[r][1], y0, o1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float y1 = acc1[r] * inv;  // channel 16 + 4q + r
+            const float y1 = acc1[r] * inv * dm1[r];  // channel 16 + 4q + r
             o0 = mfma4(w.wp[4 + r][0], y1, o0);
             o1 = mfma4(w.wp[4 + r][1], y1, o1);
         }
@@ -131,10 +124,11 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
     }
 }
 
+template <bool TRAIN>
 __global__ void __launch_bounds__(512, 2)
 b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
                      const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
-                     float *__restrict__ out) {
+                     float *__restrict__ out, TrainIO tio) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int q = lane >> 4, j = lane & 15;
@@ -212,14 +206,31 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
 
     // ---- residual blocks, two per iteration so that both weight sets have static register names ----
     float *xin = xa, *xout = xb;
+    const int nslot = a.n_blocks + 1;
+    auto save_acts = [&](const float *src, int slot) {  // block input -> acts[n][slot][t][c]
+        if constexpr (TRAIN) {
+            for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
+                const int R = i >> 3, c4 = (i & 7) * 4;
+                const int g = R / T, t = R - g * T;
+                *reinterpret_cast<f32x4 *>(tio.acts + (((size_t)(n0 + g) * nslot + slot) * T + t) * C + c4) =
+                    *reinterpret_cast<const f32x4 *>(src + (size_t)R * SX + c4);
+            }
+        }
+    };
+    const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
+    const int dstride = a.n_blocks * C;
     for (int blk = 0; blk < a.n_blocks; blk += 2) {
         if (blk + 1 < a.n_blocks) load_block(wB, Wb + (size_t)(blk + 1) * kBlockFloats, lane, q);
         __syncthreads();  // xin complete
-        run_block(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout);
+        save_acts(xin, blk);
+        run_block<TRAIN>(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout,
+                         drop0 ? drop0 + (size_t)blk * C : nullptr, dstride);
         if (blk + 1 < a.n_blocks) {
             if (blk + 2 < a.n_blocks) load_block(wA, Wb + (size_t)(blk + 2) * kBlockFloats, lane, q);
             __syncthreads();
-            run_block(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin);
+            save_acts(xout, blk + 1);
+            run_block<TRAIN>(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin,
+                             drop0 ? drop0 + (size_t)(blk + 1) * C : nullptr, dstride);
         } else {
             float *tmp = xin;
             xin = xout;
@@ -227,6 +238,8 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         }
     }
     __syncthreads();
+    save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
+    if constexpr (TRAIN) __syncthreads();
     // final relu in place (xin = TCN output); optional tap to global as (N, T, 32) == Keras Flatten order
     for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
         const int R = i >> 3, c4 = (i & 7) * 4;
@@ -241,7 +254,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     // ---- Dense layers on the flattened trunk: D[o][g] = sum_k WhT[o][k] * flat[g][k], k = t*32 + c ----
     // A (weights) pre-packed per M-tile as [k/16][lane][4]: one 16-byte load feeds four MFMA steps.
     // Waves beyond the number of M-tiles split the k range (partial sums are added in the epilogue).
-    float *pre = xout;  // scratch [nks][kMaxG][64]: the other activation buffer is free now
+    float *pre = xout;  // scratch [nks][kMaxG][kPS]: the other activation buffer is free now
     const int steps4 = a.D / 16;
     const int nks = max(1, nw / a.n_mt);
     {
@@ -266,20 +279,27 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             }
             accA += accB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pre[(ks * kMaxG + j) * 64 + 16 * mt + 4 * q + r] = accA[r];
+            for (int r = 0; r < 4; ++r) pre[(ks * kMaxG + j) * kPS + 16 * mt + 4 * q + r] = accA[r];
         }
     }
     __syncthreads();
     if (nks > 1) {
-        for (int i = threadIdx.x; i < kMaxG * 64; i += blockDim.x) {
+        for (int i = threadIdx.x; i < kMaxG * kPS; i += blockDim.x) {
             float v = pre[i];
-            for (int k2 = 1; k2 < nks; ++k2) v += pre[k2 * kMaxG * 64 + i];
+            for (int k2 = 1; k2 < nks; ++k2) v += pre[k2 * kMaxG * kPS + i];
             pre[i] = v;
         }
         __syncthreads();
     }
     // ---- BN / relu / output Dense / activations: one thread per (patch, head), one per patch for 3C ----
     const float *bh = WhA + (size_t)a.n_mt * steps4 * 64 * 4;  // NH biases follow the packed weights
+    if constexpr (TRAIN) {  // training: the batch-statistics heads run in smh_train.hip on `pre`
+        for (int i = threadIdx.x; i < g_here * kPS; i += blockDim.x) {
+            const int p = i / kPS, o = i - p * kPS;
+            tio.pre[(size_t)(n0 + p) * kPS + o] = o < a.NH ? pre[p * kPS + o] + bh[o] : 0.f;
+        }
+        return;
+    }
     const int tid = threadIdx.x;
     if (tid < g_here * a.n_heads) {
         const int p = tid / a.n_heads, h = tid - p * a.n_heads;
@@ -296,7 +316,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
 #pragma unroll
         for (int i = 0; i < kHidden; ++i) {
             const int o = a.n_classes + h * kHidden + i;
-            float v = pre[p * 64 + o] + bh[o];
+            float v = pre[p * kPS + o] + bh[o];
             v = (v - mean[i]) / sqrtf(var[i] + kBnEps);
             v = v * gamma[i] + beta[i];
             hid[i] = fmaxf(v, 0.f);
@@ -311,102 +331,36 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     } else if (tid >= 128 && tid < 128 + g_here) {
         const int p = tid - 128;
         float mxl = -INFINITY;
-        for (int c = 0; c < a.n_classes; ++c) mxl = fmaxf(mxl, pre[p * 64 + c] + bh[c]);
+        for (int c = 0; c < a.n_classes; ++c) mxl = fmaxf(mxl, pre[p * kPS + c] + bh[c]);
         float den = 0.f;
-        for (int c = 0; c < a.n_classes; ++c) den += expf(pre[p * 64 + c] + bh[c] - mxl);
+        for (int c = 0; c < a.n_classes; ++c) den += expf(pre[p * kPS + c] + bh[c] - mxl);
         const int col = a.out_dim - a.n_classes;
         for (int c = 0; c < a.n_classes; ++c)
-            out[(size_t)(n0 + p) * a.out_dim + col + c] = expf(pre[p * 64 + c] + bh[c] - mxl) / den;
+            out[(size_t)(n0 + p) * a.out_dim + col + c] = expf(pre[p * kPS + c] + bh[c] - mxl) / den;
     }
 }
 
-}  // namespace
-
-struct smh_model {
-    smh_model_cfg cfg;
-    int n_blocks, n_heads, NH, n_mt, D, out_dim, FQ;
-    int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
-    size_t n_params;
-    float *d_W0 = nullptr;   // layer-0 A operands + bias0
-    float *d_Wb = nullptr;   // per-block packed weights
-    float *d_WhA = nullptr;  // Dense-on-trunk weights in A-operand order + biases
-    float *d_hp = nullptr;   // per-head BN / out params
-    size_t nW0, nWb, nWhA, nhp;
-};
-
-extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
-    SMH_REQUIRE(cfg && out, "smh_model_create: null argument");
-    SMH_REQUIRE(cfg->nb_filters == C, "B3_MTL kernel is tiled for nb_filters=32 (got %d)", cfg->nb_filters);
-    SMH_REQUIRE(cfg->kernel_size == 3, "B3_MTL kernel supports kernel_size=3 (got %d)", cfg->kernel_size);
-    SMH_REQUIRE(cfg->n_classes == 3 || cfg->n_classes == 5, "n_classes must be 3 or 5 (got %d)", cfg->n_classes);
-    SMH_REQUIRE(cfg->n_feat >= 1 && cfg->patch_size >= 1 && cfg->patch_size <= 512, "bad n_feat/patch_size");
-    SMH_REQUIRE(cfg->nb_stacks >= 1 && cfg->n_dilations >= 1 && cfg->n_dilations <= 16, "bad stacks/dilations");
-    SMH_REQUIRE(smh_device_count() > 0, "no HIP device visible: libsmh has no CPU path");
-    smh_model *m = new smh_model();
-    m->cfg = *cfg;
-    m->n_blocks = cfg->nb_stacks * cfg->n_dilations;
-    if (cfg->n_classes == 5) {  // 5_class_classification.py:150-215: S, M, N, R(3)
-        m->n_heads = 4;
-        const int od[4] = {1, 1, 1, 3}, sg[4] = {1, 1, 1, 0};
-        for (int i = 0; i < 4; ++i) m->head_odim[i] = od[i], m->head_sigmoid[i] = sg[i];
-    } else {  // proposed_architectures.py:25-80: S, M, R(2)
-        m->n_heads = 3;
-        const int od[3] = {1, 1, 2}, sg[3] = {1, 1, 0};
-        for (int i = 0; i < 3; ++i) m->head_odim[i] = od[i], m->head_sigmoid[i] = sg[i];
+// gather kernel: packed[i] = map[i] ? flat[map[i] - 1] : 0
+__global__ void repack_kernel(const float *__restrict__ flat, const int *__restrict__ map, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int m = map[i];
+        dst[i] = m ? flat[m - 1] : 0.f;
     }
-    m->D = cfg->patch_size * C;
-    m->NH = cfg->n_classes + kHidden * m->n_heads;
-    m->n_mt = (m->NH + 15) / 16;
-    m->out_dim = cfg->n_classes;
-    for (int i = 0; i < m->n_heads; ++i) m->out_dim += m->head_odim[i];
-    m->FQ = (cfg->n_feat + 3) / 4;
-    size_t n = (size_t)cfg->n_feat * C + C;
-    n += (size_t)m->n_blocks * (3 * C * C + C + C * C + C);
-    n += (size_t)m->D * cfg->n_classes + cfg->n_classes;
-    for (int i = 0; i < m->n_heads; ++i)
-        n += (size_t)m->D * kHidden + kHidden + 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
-    m->n_params = n;
-    m->nW0 = (size_t)m->FQ * 2 * 64 + 32;
-    m->nWb = (size_t)m->n_blocks * kBlockFloats;
-    m->nWhA = (size_t)m->n_mt * (m->D / 16) * 64 * 4 + (size_t)m->n_mt * 16;
-    m->nhp = 0;
-    for (int i = 0; i < m->n_heads; ++i) m->nhp += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
-    hipError_t e = hipMalloc((void **)&m->d_W0, m->nW0 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Wb, m->nWb * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_WhA, m->nWhA * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_hp, m->nhp * sizeof(float));
-    if (e != hipSuccess) {
-        smh_model_destroy(m);
-        return smh::set_error(SMH_E_HIP, "smh_model_create: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    *out = m;
-    return SMH_OK;
 }
 
-extern "C" void smh_model_destroy(smh_model *m) {
-    if (!m) return;
-    (void)hipFree(m->d_W0);
-    (void)hipFree(m->d_Wb);
-    (void)hipFree(m->d_WhA);
-    (void)hipFree(m->d_hp);
-    delete m;
-}
-
-extern "C" size_t smh_model_num_params(const smh_model *m) { return m ? m->n_params : 0; }
-extern "C" int smh_model_out_dim(const smh_model *m) { return m ? m->out_dim : SMH_E_INVALID; }
-
+// Host packing of canonical weights `h` into the four operand buffers (used once, on an iota vector,
+// to build the device gather map).
 // Canonical flat order (Keras array layouts):
 //   initial_conv kernel (1,F,32), bias(32); per block [conv kernel (3,32,32), bias, conv1x1 kernel (1,32,32), bias];
 //   3C kernel (D,ncls), bias; per head [dense kernel (D,16), bias, gamma, beta, moving_mean, moving_var,
 //   out kernel (16,odim), out bias].
-extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, void *stream) {
-    SMH_REQUIRE(m && h, "smh_model_set_weights: null argument");
-    SMH_REQUIRE(n == m->n_params, "smh_model_set_weights: got %zu floats, model has %zu", n, m->n_params);
+static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0, std::vector<float> &Wb,
+                      std::vector<float> &WhA, std::vector<float> &hp) {
     const int F = m->cfg.n_feat, FQ = m->FQ, D = m->D, NH = m->NH, ncls = m->cfg.n_classes;
-    std::vector<float> W0(m->nW0, 0.f), Wb(m->nWb, 0.f), WhA(m->nWhA, 0.f), hp(m->nhp, 0.f);
+    W0.assign(m->nW0, 0.f), Wb.assign(m->nWb, 0.f), WhA.assign(m->nWhA, 0.f), hp.assign(m->nhp, 0.f);
     std::vector<float> Wh((size_t)D * NH, 0.f), bhv((size_t)m->n_mt * 16, 0.f);
     const float *p = h;
-    // layer 0: A[s][m'][lane] = W0[f = q*FQ + s][16m' + i]
     for (int s = 0; s < FQ; ++s)
         for (int mt = 0; mt < 2; ++mt)
             for (int lane = 0; lane < 64; ++lane) {
@@ -443,7 +397,6 @@ extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, voi
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64, b1, C * sizeof(float));
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64 + 32, b2, C * sizeof(float));
     }
-    // Dense-on-trunk matrix, column order [3C | head0 dense16 | head1 dense16 | ...]
     const float *k3c = p;
     p += (size_t)D * ncls;
     const float *b3c = p;
@@ -476,26 +429,42 @@ extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, voi
                     WhA[(((size_t)mt * steps4 + s4) * 64 + lane) * 4 + e] = o < NH ? Wh[(size_t)k * NH + o] : 0.f;
                 }
     std::memcpy(&WhA[(size_t)m->n_mt * steps4 * 64 * 4], bhv.data(), bhv.size() * sizeof(float));
-    hipStream_t st = (hipStream_t)stream;
-    SMH_CHECK_HIP(hipMemcpyAsync(m->d_W0, W0.data(), W0.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    SMH_CHECK_HIP(hipMemcpyAsync(m->d_Wb, Wb.data(), Wb.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    SMH_CHECK_HIP(hipMemcpyAsync(m->d_WhA, WhA.data(), WhA.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    SMH_CHECK_HIP(hipMemcpyAsync(m->d_hp, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    SMH_CHECK_HIP(hipStreamSynchronize(st));  // the staging vectors die here
-    return SMH_OK;
 }
 
-extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk,
-                                     void *stream) {
-    SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_f32: null argument");
-    SMH_REQUIRE(N >= 0, "smh_model_forward_f32: N=%d", N);
-    if (N == 0) return SMH_OK;
+}  // namespace
+
+namespace smh_tcn {
+
+Offsets offsets(const smh_model *m) {
+    Offsets o;
+    const size_t F = m->cfg.n_feat, D = m->D, ncls = m->cfg.n_classes;
+    size_t p = 0;
+    o.w0_k = p, p += F * C;
+    o.w0_b = p, p += C;
+    o.blk0 = p, o.blk_stride = 3 * C * C + C + C * C + C;
+    p += (size_t)m->n_blocks * o.blk_stride;
+    o.c3_k = p, p += D * ncls;
+    o.c3_b = p, p += ncls;
+    for (int h = 0; h < m->n_heads; ++h) {
+        o.head[h] = p;
+        p += D * kHidden + kHidden + 4 * kHidden + (size_t)kHidden * m->head_odim[h] + m->head_odim[h];
+    }
+    return o;
+}
+
+int repack(smh_model *m, hipStream_t st) {
+    const size_t n = m->nW0 + m->nWb + m->nWhA + m->nhp;
+    // the four operand buffers are one allocation: d_W0 is its base
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->d_flat, m->d_map, m->d_W0, n);
+    return smh::launch_status("repack_kernel");
+}
+
+void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
+    TcnArgs &a = *pa;
     const int T = m->cfg.patch_size;
-    TcnArgs a;
     a.N = N, a.T = T, a.F = m->cfg.n_feat, a.FQ = m->FQ, a.n_blocks = m->n_blocks, a.n_dil = m->cfg.n_dilations;
     a.vec_ok = (a.F % 4 == 0) && (a.FQ % 4 == 0) && (a.FQ * 4 == a.F);
-    if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
-    a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
+    a.skip_heads = 0;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
     for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
@@ -509,15 +478,137 @@ extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N
     if (G > gmax) G = gmax;
     a.G = G;
     int GRP = ((G * T + 15) / 16) * 16;
-    if (GRP * SX < 8 * kMaxG * 64) GRP = (8 * kMaxG * 64 + SX - 1) / SX;  // the head scratch lives in one buffer
+    if (GRP * SX < 2 * kMaxG * kPS) GRP = (2 * kMaxG * kPS + SX - 1) / SX;  // the head scratch lives in one buffer
     if (GRP * SX < m->FQ * 2 * 64) GRP = (m->FQ * 2 * 64 + SX - 1) / SX;  // layer-0 A operands are staged there
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
-    const size_t lds = sizeof(float) * 2 * (size_t)GRP * SX;
-    SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", T);
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-    hipLaunchKernelGGL(b3mtl_forward_kernel, dim3((N + G - 1) / G), dim3(512), lds, (hipStream_t)stream, a, d_x, m->d_W0,
-                       m->d_Wb, m->d_WhA, m->d_hp, d_trunk, d_out);
+    *plds = sizeof(float) * 2 * (size_t)GRP * SX;
+}
+
+int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
+                   hipStream_t st) {
+    TcnArgs a;
+    size_t lds;
+    fill_args(m, N, &a, &lds);
+    if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
+    a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
+    SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
+    const dim3 grid((N + a.G - 1) / a.G), block(512);
+    if (tio) {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(b3mtl_forward_kernel<true>, grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA, m->d_hp,
+                           d_trunk, d_out, *tio);
+    } else {
+        TrainIO none{nullptr, nullptr, nullptr};
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(b3mtl_forward_kernel<false>, grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA, m->d_hp,
+                           d_trunk, d_out, none);
+    }
     return smh::launch_status("b3mtl_forward_kernel");
+}
+
+}  // namespace smh_tcn
+
+extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
+    SMH_REQUIRE(cfg && out, "smh_model_create: null argument");
+    SMH_REQUIRE(cfg->nb_filters == C, "B3_MTL kernel is tiled for nb_filters=32 (got %d)", cfg->nb_filters);
+    SMH_REQUIRE(cfg->kernel_size == 3, "B3_MTL kernel supports kernel_size=3 (got %d)", cfg->kernel_size);
+    SMH_REQUIRE(cfg->n_classes == 3 || cfg->n_classes == 5, "n_classes must be 3 or 5 (got %d)", cfg->n_classes);
+    SMH_REQUIRE(cfg->n_feat >= 1 && cfg->patch_size >= 1 && cfg->patch_size <= 512, "bad n_feat/patch_size");
+    SMH_REQUIRE(cfg->nb_stacks >= 1 && cfg->n_dilations >= 1 && cfg->n_dilations <= 16, "bad stacks/dilations");
+    SMH_REQUIRE(smh_device_count() > 0, "no HIP device visible: libsmh has no CPU path");
+    smh_model *m = new smh_model();
+    m->cfg = *cfg;
+    m->n_blocks = cfg->nb_stacks * cfg->n_dilations;
+    if (cfg->n_classes == 5) {  // 5_class_classification.py:150-215: S, M, N, R(3)
+        m->n_heads = 4;
+        const int od[4] = {1, 1, 1, 3}, sg[4] = {1, 1, 1, 0};
+        for (int i = 0; i < 4; ++i) m->head_odim[i] = od[i], m->head_sigmoid[i] = sg[i];
+    } else {  // proposed_architectures.py:25-80: S, M, R(2)
+        m->n_heads = 3;
+        const int od[3] = {1, 1, 2}, sg[3] = {1, 1, 0};
+        for (int i = 0; i < 3; ++i) m->head_odim[i] = od[i], m->head_sigmoid[i] = sg[i];
+    }
+    m->D = cfg->patch_size * C;
+    m->NH = cfg->n_classes + kHidden * m->n_heads;
+    m->n_mt = (m->NH + 15) / 16;
+    m->out_dim = cfg->n_classes;
+    for (int i = 0; i < m->n_heads; ++i) m->out_dim += m->head_odim[i];
+    m->FQ = (cfg->n_feat + 3) / 4;
+    size_t n = (size_t)cfg->n_feat * C + C;
+    n += (size_t)m->n_blocks * (3 * C * C + C + C * C + C);
+    n += (size_t)m->D * cfg->n_classes + cfg->n_classes;
+    for (int i = 0; i < m->n_heads; ++i)
+        n += (size_t)m->D * kHidden + kHidden + 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
+    m->n_params = n;
+    SMH_REQUIRE(n < (1u << 24), "model too large for the float-encoded gather map");
+    m->nW0 = (size_t)m->FQ * 2 * 64 + 32;
+    m->nWb = (size_t)m->n_blocks * kBlockFloats;
+    m->nWhA = (size_t)m->n_mt * (m->D / 16) * 64 * 4 + (size_t)m->n_mt * 16;
+    m->nhp = 0;
+    for (int i = 0; i < m->n_heads; ++i) m->nhp += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
+    // gather map = the host packing applied to 1, 2, 3, ... (0 marks padding)
+    std::vector<float> iota(n), W0, Wb, WhA, hp;
+    for (size_t i = 0; i < n; ++i) iota[i] = (float)(i + 1);
+    pack_host(m, iota.data(), W0, Wb, WhA, hp);
+    std::vector<int> map;
+    map.reserve(m->nW0 + m->nWb + m->nWhA + m->nhp);
+    for (auto *v : {&W0, &Wb, &WhA, &hp})
+        for (float f : *v) map.push_back((int)f);
+    const size_t npk = map.size();
+    hipError_t e = hipMalloc((void **)&m->d_flat, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_W0, npk * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_map, npk * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(m->d_map, map.data(), npk * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(m->d_flat, 0, n * sizeof(float));
+    if (e != hipSuccess) {
+        smh_model_destroy(m);
+        return smh::set_error(SMH_E_HIP, "smh_model_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    m->d_Wb = m->d_W0 + m->nW0;
+    m->d_WhA = m->d_Wb + m->nWb;
+    m->d_hp = m->d_WhA + m->nWhA;
+    *out = m;
+    return SMH_OK;
+}
+
+extern "C" void smh_model_destroy(smh_model *m) {
+    if (!m) return;
+    (void)hipFree(m->d_flat);
+    (void)hipFree(m->d_W0);  // base of the four operand buffers
+    (void)hipFree(m->d_map);
+    delete m;
+}
+
+extern "C" size_t smh_model_num_params(const smh_model *m) { return m ? m->n_params : 0; }
+extern "C" int smh_model_out_dim(const smh_model *m) { return m ? m->out_dim : SMH_E_INVALID; }
+
+extern "C" int smh_model_set_weights(smh_model *m, const float *h, size_t n, void *stream) {
+    SMH_REQUIRE(m && h, "smh_model_set_weights: null argument");
+    SMH_REQUIRE(n == m->n_params, "smh_model_set_weights: got %zu floats, model has %zu", n, m->n_params);
+    hipStream_t st = (hipStream_t)stream;
+    SMH_CHECK_HIP(hipMemcpyAsync(m->d_flat, h, n * sizeof(float), hipMemcpyHostToDevice, st));
+    int rc = smh_tcn::repack(m, st);
+    if (rc) return rc;
+    SMH_CHECK_HIP(hipStreamSynchronize(st));  // the caller's host buffer may die after return
+    return SMH_OK;
+}
+
+extern "C" int smh_model_get_weights(const smh_model *m, float *h, size_t n, void *stream) {
+    SMH_REQUIRE(m && h, "smh_model_get_weights: null argument");
+    SMH_REQUIRE(n == m->n_params, "smh_model_get_weights: got room for %zu floats, model has %zu", n, m->n_params);
+    hipStream_t st = (hipStream_t)stream;
+    SMH_CHECK_HIP(hipMemcpyAsync(h, m->d_flat, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    SMH_CHECK_HIP(hipStreamSynchronize(st));
+    return SMH_OK;
+}
+
+extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk,
+                                     void *stream) {
+    SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_f32: null argument");
+    SMH_REQUIRE(N >= 0, "smh_model_forward_f32: N=%d", N);
+    if (N == 0) return SMH_OK;
+    return smh_tcn::launch_forward(m, d_x, N, d_out, d_trunk, nullptr, (hipStream_t)stream);
 }

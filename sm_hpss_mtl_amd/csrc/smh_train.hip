@@ -1,0 +1,530 @@
+// a14: one training step of B3_MTL -- what `model.fit` runs per batch for the model compiled at
+// lib/proposed_architectures.py:156-165 (losses S,M(,N): binary_crossentropy, R: mean_squared_error,
+// 3C: categorical_crossentropy, l2(0.01) on the Dense(16) kernels, SGD(momentum 0.9, clipnorm=1)).
+// Arithmetic restated in oracle/b3_mtl_train.py (pinned against torch autograd on the CPU).
+//
+//   smh_train_step_f32      = forward (MFMA kernel of smh_tcn.hip, TRAIN variant: saves every block input,
+//                             applies the SpatialDropout1D masks) -> heads_train_kernel (batch-statistics
+//                             BN, Dropout, losses, d loss / d pre) -> tcn_backward_kernel.
+//   smh_trainer_apply_sgd_f32 = per-tensor clipnorm, momentum, BN moving averages, device-side repack.
+// Round-1 scope: CORRECT and device-resident.  The backward kernel recomputes each block from its saved
+// input with plain VALU loops in LDS and accumulates weight gradients with float atomics; moving it onto
+// the MFMA tiling of the forward kernel is the obvious next step.
+#include <cstring>
+#include <vector>
+
+#include "smh_model.h"
+
+using namespace smh_tcn;
+
+namespace {
+
+constexpr float kKerasEps = 1e-7f;
+constexpr float kBnMomentum = 0.99f;
+constexpr float kL2 = 0.01f;
+constexpr int kBG = 2;        // patches per workgroup in the backward kernel
+constexpr int kBS = 33;       // LDS row stride (floats) of the backward buffers
+constexpr int kBThreads = 512;
+
+struct HeadsArgs {
+    int N, D, NH, n_classes, n_heads, out_dim;
+    int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
+    float lw[kMaxHeads + 1];
+    size_t goff_head[kMaxHeads];  // canonical offset of each head's first tensor (dense kernel)
+    size_t goff_c3b;              // canonical offset of the 3C bias
+};
+
+// Single workgroup: the batch-statistics part of the network is tiny (N x 51 values).
+__global__ void __launch_bounds__(1024)
+heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__restrict__ y, const float *__restrict__ hp,
+                   const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
+                   float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses) {
+    __shared__ float s_mean[64], s_inv[64], s_sum1[64], s_sum2[64], s_dgamma[64], s_dbeta[64], s_dbias[64];
+    __shared__ float s_dwo[kMaxHeads * kHidden * 3], s_dbo[kMaxHeads * 3], s_loss[kMaxHeads + 2], s_db3[8];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int N = a.N, ncls = a.n_classes, nh = a.n_heads, NJ = nh * kHidden;
+    for (int i = tid; i < 64; i += nt) s_sum1[i] = s_sum2[i] = s_dgamma[i] = s_dbeta[i] = s_dbias[i] = 0.f;
+    for (int i = tid; i < kMaxHeads * kHidden * 3; i += nt) s_dwo[i] = 0.f;
+    if (tid < kMaxHeads * 3) s_dbo[tid] = 0.f;
+    if (tid < kMaxHeads + 2) s_loss[tid] = 0.f;
+    if (tid < 8) s_db3[tid] = 0.f;
+    // A: batch statistics of every hidden unit (population variance, two passes)
+    if (tid < NJ) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += pre[(size_t)n * kPS + ncls + tid];
+        const float mean = s / (float)N;
+        float q = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float d = pre[(size_t)n * kPS + ncls + tid] - mean;
+            q += d * d;
+        }
+        const float var = q / (float)N;
+        s_mean[tid] = mean;
+        s_inv[tid] = 1.0f / sqrtf(var + kBnEps);
+        const int h = tid / kHidden, i = tid % kHidden;
+        bnstat[h * 32 + i] = mean;
+        bnstat[h * 32 + 16 + i] = var;
+    }
+    __syncthreads();
+    // B: per (sample, head): forward through BN / relu / dropout / output Dense, loss, and gradients
+    for (int it = tid; it < N * nh; it += nt) {
+        const int n = it / nh, h = it - n * nh;
+        const float *ph = hp;
+        int col = 0;
+        for (int k = 0; k < h; ++k) {
+            ph += 4 * kHidden + kHidden * a.head_odim[k] + a.head_odim[k];
+            col += a.head_odim[k];
+        }
+        const float *gamma = ph, *beta = ph + 16, *wo = ph + 64;
+        const int od = a.head_odim[h];
+        const float *bo = wo + kHidden * od;
+        float xh[kHidden], bn[kHidden], ad[kHidden], dm[kHidden];
+        float zo[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < od; ++c) zo[c] = bo[c];
+#pragma unroll
+        for (int i = 0; i < kHidden; ++i) {
+            const int j = h * kHidden + i;
+            xh[i] = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
+            bn[i] = xh[i] * gamma[i] + beta[i];
+            dm[i] = drop ? drop[((size_t)n * nh + h) * kHidden + i] : 1.0f;
+            ad[i] = fmaxf(bn[i], 0.f) * dm[i];
+            for (int c = 0; c < od; ++c) zo[c] = fmaf(ad[i], wo[i * od + c], zo[c]);
+        }
+        float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f;
+        for (int c = 0; c < od; ++c) {
+            const float t = y[(size_t)n * a.out_dim + col + c];
+            if (a.head_sigmoid[h]) {
+                const float o = 1.0f / (1.0f + expf(-zo[c]));
+                const float oc = fminf(fmaxf(o, kKerasEps), 1.0f - kKerasEps);
+                lsum += -(t * logf(oc + kKerasEps) + (1.0f - t) * logf(1.0f - oc + kKerasEps));
+                const bool inside = (o > kKerasEps) && (o < 1.0f - kKerasEps);
+                const float doc = -(t / (oc + kKerasEps) - (1.0f - t) / (1.0f - oc + kKerasEps)) / (float)(N * od);
+                dzo[c] = inside ? doc * o * (1.0f - o) : 0.f;
+            } else {
+                const float d = zo[c] - t;
+                lsum += d * d;
+                dzo[c] = 2.0f * d / (float)(N * od);
+            }
+            dzo[c] *= a.lw[h];
+            atomicAdd(&s_dbo[h * 3 + c], dzo[c]);
+        }
+        atomicAdd(&s_loss[h], lsum / (float)(N * od));
+#pragma unroll
+        for (int i = 0; i < kHidden; ++i) {
+            const int j = h * kHidden + i;
+            float da = 0.f;
+            for (int c = 0; c < od; ++c) {
+                da = fmaf(dzo[c], wo[i * od + c], da);
+                atomicAdd(&s_dwo[(h * kHidden + i) * 3 + c], ad[i] * dzo[c]);
+            }
+            const float dbn = bn[i] > 0.f ? da * dm[i] : 0.f;
+            const float dxhat = dbn * gamma[i];
+            dxh[(size_t)n * kPS + j] = dxhat;
+            atomicAdd(&s_dgamma[j], dbn * xh[i]);
+            atomicAdd(&s_dbeta[j], dbn);
+            atomicAdd(&s_sum1[j], dxhat);
+            atomicAdd(&s_sum2[j], dxhat * xh[i]);
+        }
+    }
+    __syncthreads();
+    // C: BN backward to the Dense(16) pre-activations
+    for (int it = tid; it < N * NJ; it += nt) {
+        const int n = it / NJ, j = it - n * NJ;
+        const float xhat = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
+        const float d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)n * kPS + j] - s_sum1[j] - xhat * s_sum2[j]);
+        dpre[(size_t)n * kPS + ncls + j] = d;
+        atomicAdd(&s_dbias[j], d);
+    }
+    // D: softmax + categorical cross-entropy
+    for (int n = tid; n < N; n += nt) {
+        float mx = -INFINITY, p[8], t[8];
+        for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, pre[(size_t)n * kPS + c]);
+        float den = 0.f;
+        for (int c = 0; c < ncls; ++c) den += (p[c] = expf(pre[(size_t)n * kPS + c] - mx));
+        int am = 0, at = 0;
+        float l = 0.f;
+        for (int c = 0; c < ncls; ++c) {
+            p[c] /= den;
+            t[c] = y[(size_t)n * a.out_dim + (a.out_dim - ncls) + c];
+            l -= t[c] * logf(fminf(fmaxf(p[c], kKerasEps), 1.0f - kKerasEps));
+            if (p[c] > p[am]) am = c;
+            if (t[c] > t[at]) at = c;
+        }
+        for (int c = 0; c < ncls; ++c) {
+            const float d = (p[c] - t[c]) / (float)N * a.lw[nh];
+            dpre[(size_t)n * kPS + c] = d;
+            atomicAdd(&s_db3[c], d);
+        }
+        for (int c = ncls + NJ; c < kPS; ++c) dpre[(size_t)n * kPS + c] = 0.f;
+        atomicAdd(&s_loss[nh], l / (float)N);
+        atomicAdd(&s_loss[nh + 1], am == at ? 1.0f / (float)N : 0.f);
+    }
+    __syncthreads();
+    // E: gradients of the small tensors (this workgroup is their only writer) and the losses
+    for (int j = tid; j < NJ; j += nt) {
+        const int h = j / kHidden, i = j % kHidden;
+        float *gh = grad + a.goff_head[h] + (size_t)a.D * kHidden;  // after the dense kernel
+        gh[i] = s_dbias[j];
+        gh[16 + i] = s_dgamma[j];
+        gh[32 + i] = s_dbeta[j];
+        const int od = a.head_odim[h];
+        for (int c = 0; c < od; ++c) gh[16 + 64 + i * od + c] = s_dwo[j * 3 + c];
+        if (i < od) gh[16 + 64 + kHidden * od + i] = s_dbo[h * 3 + i];
+    }
+    if (tid < ncls) grad[a.goff_c3b + tid] = s_db3[tid];
+    if (tid == 0) {
+        float total = 0.f;
+        for (int h = 0; h < nh; ++h) {
+            losses[h] = s_loss[h];
+            total += a.lw[h] * s_loss[h];
+        }
+        losses[nh] = s_loss[nh];
+        total += a.lw[nh] * s_loss[nh];
+        losses[nh + 1] = total;           // without the l2 term (added by the host from the weights' norms)
+        losses[nh + 2] = s_loss[nh + 1];  // 3C accuracy
+    }
+}
+
+struct BwdArgs {
+    int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
+    Offsets off;
+};
+
+// One workgroup = kBG patches.  All buffers are (rows = g*T + t, channel) with stride kBS.
+__global__ void __launch_bounds__(kBThreads)
+tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw, const float *__restrict__ acts,
+                    const float *__restrict__ drop, const float *__restrict__ dpre, float *__restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int T = a.T, nslot = a.n_blocks + 1;
+    const int n0 = blockIdx.x * kBG;
+    const int g_here = min(kBG, a.N - n0);
+    const int rows = g_here * T, RP = kBG * T;
+    float *G = sm, *Xs = G + (size_t)RP * kBS, *U = Xs + (size_t)RP * kBS, *Y = U + (size_t)RP * kBS;
+    float *W1 = Y + (size_t)RP * kBS;       // [3][32][32]
+    float *W2 = W1 + 3 * C * C;             // [32][32]
+    float *B1 = W2 + C * C;                 // [32]
+    float *rowm = B1 + C;                   // per row: m
+    float *rowmx = rowm + RP;               // per row: max
+    float *dps = rowmx + RP;                // [kBG][kPS] d loss / d pre
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    for (int i = tid; i < g_here * kPS; i += nt) dps[i] = dpre[(size_t)n0 * kPS + i];
+    __syncthreads();
+    // ---- Dense-on-trunk backward: G = relu'(x) * (dpre @ Wh^T);  dWh += flat^T dpre --------------------
+    for (int i = tid; i < rows * C; i += nt) {
+        const int R = i / C, c = i - R * C;
+        const int g = R / T, t = R - g * T;
+        const size_t k = (size_t)t * C + c;
+        const float xpre = acts[(((size_t)(n0 + g) * nslot + a.n_blocks) * T + t) * C + c];
+        const float fl = fmaxf(xpre, 0.f);
+        float acc = 0.f;
+        const float *dp = dps + g * kPS;
+        for (int o = 0; o < a.n_classes; ++o) {
+            acc = fmaf(dp[o], flatw[a.off.c3_k + k * a.n_classes + o], acc);
+            if (fl != 0.f) atomicAdd(&grad[a.off.c3_k + k * a.n_classes + o], fl * dp[o]);
+        }
+        for (int h = 0; h < a.n_heads; ++h) {
+            const size_t base = a.off.head[h] + k * kHidden;
+            for (int j = 0; j < kHidden; ++j) {
+                const float d = dp[a.n_classes + h * kHidden + j];
+                acc = fmaf(d, flatw[base + j], acc);
+                if (fl != 0.f) atomicAdd(&grad[base + j], fl * d);
+            }
+        }
+        G[R * kBS + c] = xpre > 0.f ? acc : 0.f;
+    }
+    // ---- residual blocks, last to first ----------------------------------------------------------------
+    for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
+        const int d = 1 << (blk % a.n_dil);
+        const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+        const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
+        __syncthreads();
+        for (int i = tid; i < rows * C; i += nt) {
+            const int R = i / C, c = i - R * C;
+            const int g = R / T, t = R - g * T;
+            Xs[R * kBS + c] = acts[(((size_t)(n0 + g) * nslot + blk) * T + t) * C + c];
+        }
+        for (int i = tid; i < 3 * C * C; i += nt) W1[i] = flatw[o_k1 + i];
+        for (int i = tid; i < C * C; i += nt) W2[i] = flatw[o_k2 + i];
+        if (tid < C) B1[tid] = flatw[o_b1 + tid];
+        __syncthreads();
+        // recompute u = conv_d(x) + b1
+        for (int i = tid; i < rows * C; i += nt) {
+            const int R = i / C, co = i - R * C;
+            const int t = R % T;
+            float acc = B1[co];
+            for (int tap = 0; tap < 3; ++tap) {
+                const int off = (tap - 1) * d;
+                if (t + off < 0 || t + off >= T) continue;
+                const float *xr = Xs + (R + off) * kBS;
+                const float *w = W1 + tap * C * C + co;
+#pragma unroll 8
+                for (int c = 0; c < C; ++c) acc = fmaf(xr[c], w[c * C], acc);
+            }
+            U[R * kBS + co] = acc;
+        }
+        __syncthreads();
+        // row statistics: m = max_c relu(u) + eps ; y = relu(u)/m * mask
+        for (int i = tid; i < rows * C; i += nt) {  // 32 consecutive threads = one row (C == 32)
+            const int R = i / C, c = i - R * C;
+            const float r = fmaxf(U[R * kBS + c], 0.f);
+            float mx = r;
+            for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float m = mx + kNormEps;
+            const float mask = drop ? drop[((size_t)(n0 + R / T) * a.n_blocks + blk) * C + c] : 1.0f;
+            Y[R * kBS + c] = r / m * mask;
+            if (c == 0) rowm[R] = m, rowmx[R] = mx;
+        }
+        __syncthreads();
+        // dW2[c][co] += sum_R y[R][c] g[R][co] ; db2[co] += sum_R g[R][co]
+        for (int i = tid; i < C * C; i += nt) {
+            const int c = i / C, co = i - c * C;
+            float acc = 0.f, accb = 0.f;
+            for (int R = 0; R < rows; ++R) {
+                const float gv = G[R * kBS + co];
+                acc = fmaf(Y[R * kBS + c], gv, acc);
+                accb += gv;
+            }
+            atomicAdd(&grad[o_k2 + i], acc);
+            if (c == 0) atomicAdd(&grad[o_b2 + co], accb);
+        }
+        __syncthreads();
+        // dyn = g @ W2^T (masked) ; norm backward ; du = dr * (u > 0)  -> U
+        for (int i = tid; i < rows * C; i += nt) {
+            const int R = i / C, c = i - R * C;
+            const float *gr = G + R * kBS;
+            const float *w = W2 + c * C;
+            float dyn = 0.f;
+#pragma unroll 8
+            for (int co = 0; co < C; ++co) dyn = fmaf(gr[co], w[co], dyn);
+            const float mask = drop ? drop[((size_t)(n0 + R / T) * a.n_blocks + blk) * C + c] : 1.0f;
+            dyn *= mask;
+            const float u = U[R * kBS + c];
+            const float r = fmaxf(u, 0.f);
+            const float m = rowm[R], mx = rowmx[R];
+            float s1 = dyn * r;
+            float cnt = (r == mx) ? 1.f : 0.f;
+            for (int o = 16; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o);
+                cnt += __shfl_xor(cnt, o);
+            }
+            float dr = dyn / m;
+            if (r == mx && r > 0.f) dr -= s1 / (m * m) / cnt;
+            U[R * kBS + c] = u > 0.f ? dr : 0.f;
+        }
+        __syncthreads();
+        // dW1[tap][c][co] += sum_R x[R+off][c] du[R][co] ; db1[co] += sum_R du[R][co]
+        for (int i = tid; i < 3 * C * C; i += nt) {
+            const int tap = i / (C * C), c = (i / C) % C, co = i % C;
+            const int off = (tap - 1) * d;
+            float acc = 0.f, accb = 0.f;
+            for (int R = 0; R < rows; ++R) {
+                const int t = R % T;
+                const float duv = U[R * kBS + co];
+                accb += duv;
+                if (t + off >= 0 && t + off < T) acc = fmaf(Xs[(R + off) * kBS + c], duv, acc);
+            }
+            atomicAdd(&grad[o_k1 + i], acc);
+            if (tap == 0 && c == 0) atomicAdd(&grad[o_b1 + co], accb);
+        }
+        __syncthreads();
+        // g[R][c] += sum_tap sum_co du[R - off][co] W1[tap][c][co]
+        for (int i = tid; i < rows * C; i += nt) {
+            const int R = i / C, c = i - R * C;
+            const int t = R % T;
+            float acc = G[R * kBS + c];
+            for (int tap = 0; tap < 3; ++tap) {
+                const int off = (tap - 1) * d;
+                if (t - off < 0 || t - off >= T) continue;
+                const float *dur = U + (R - off) * kBS;
+                const float *w = W1 + tap * C * C + c * C;
+#pragma unroll 8
+                for (int co = 0; co < C; ++co) acc = fmaf(dur[co], w[co], acc);
+            }
+            G[R * kBS + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- initial Conv1D(32,1): dW0[f][c] += sum_R x[R][f] g[R][c] ; db0[c] += sum_R g[R][c] ----------------
+    for (int i = tid; i < a.F * C; i += nt) {
+        const int f = i / C, c = i - f * C;
+        float acc = 0.f, accb = 0.f;
+        for (int R = 0; R < rows; ++R) {
+            const float gv = G[R * kBS + c];
+            acc = fmaf(X[((size_t)n0 * T + R) * a.F + f], gv, acc);
+            accb += gv;
+        }
+        atomicAdd(&grad[a.off.w0_k + i], acc);
+        if (f == 0) atomicAdd(&grad[a.off.w0_b + c], accb);
+    }
+}
+
+struct Segment {
+    unsigned off, size;
+    int kind;  // 0 plain, 1 l2-regularised Dense(16) kernel, 2 BN moving_mean, 3 BN moving_variance
+    int aux;   // kinds 2/3: offset into the batch-statistics buffer
+};
+
+__global__ void seg_sumsq_kernel(const Segment *__restrict__ segs, const float *__restrict__ w, float *__restrict__ grad,
+                                 float grad_scale, float *__restrict__ sumsq) {
+    __shared__ float red[256];
+    const Segment s = segs[blockIdx.x];
+    float acc = 0.f;
+    if (s.kind <= 1)
+        for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
+            float g = grad[s.off + i] * grad_scale;
+            if (s.kind == 1) g += 2.0f * kL2 * w[s.off + i];  // d/dw of l2 * sum(w^2)
+            grad[s.off + i] = g;
+            acc = fmaf(g, g, acc);
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = red[0];
+}
+
+__global__ void seg_sgd_kernel(const Segment *__restrict__ segs, float *__restrict__ w, const float *__restrict__ grad,
+                               float *__restrict__ vel, const float *__restrict__ sumsq, const float *__restrict__ bnstat,
+                               float lr, float momentum, float clipnorm) {
+    const Segment s = segs[blockIdx.x];
+    if (s.kind >= 2) {
+        for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x)
+            w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * bnstat[s.aux + i];
+        return;
+    }
+    const float nrm = sqrtf(sumsq[blockIdx.x]);
+    const float scale = (clipnorm > 0.f && nrm > clipnorm) ? clipnorm / nrm : 1.0f;
+    for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
+        const float v = momentum * vel[s.off + i] - lr * grad[s.off + i] * scale;
+        vel[s.off + i] = v;
+        w[s.off + i] += v;
+    }
+}
+
+}  // namespace
+
+struct smh_trainer {
+    smh_model *m;
+    int max_batch, nseg;
+    float *d_acts = nullptr, *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr, *d_grad = nullptr, *d_vel = nullptr;
+    float *d_bnstat = nullptr, *d_sumsq = nullptr, *d_scratch_out = nullptr;
+    Segment *d_segs = nullptr;
+};
+
+extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out) {
+    SMH_REQUIRE(m && out && max_batch >= 1, "smh_trainer_create: bad argument");
+    smh_trainer *t = new smh_trainer();
+    t->m = m, t->max_batch = max_batch;
+    const Offsets off = offsets(m);
+    std::vector<Segment> segs;
+    auto add = [&](size_t o, size_t n, int kind, int aux) { segs.push_back(Segment{(unsigned)o, (unsigned)n, kind, aux}); };
+    add(off.w0_k, (size_t)m->cfg.n_feat * C, 0, 0);
+    add(off.w0_b, C, 0, 0);
+    for (int b = 0; b < m->n_blocks; ++b) {
+        const size_t w = off.blk0 + (size_t)b * off.blk_stride;
+        add(w, 3 * C * C, 0, 0);
+        add(w + 3 * C * C, C, 0, 0);
+        add(w + 3 * C * C + C, C * C, 0, 0);
+        add(w + 3 * C * C + C + C * C, C, 0, 0);
+    }
+    add(off.c3_k, (size_t)m->D * m->cfg.n_classes, 0, 0);
+    add(off.c3_b, m->cfg.n_classes, 0, 0);
+    for (int h = 0; h < m->n_heads; ++h) {
+        size_t p = off.head[h];
+        add(p, (size_t)m->D * kHidden, 1, 0), p += (size_t)m->D * kHidden;
+        add(p, kHidden, 0, 0), p += kHidden;                 // dense bias
+        add(p, kHidden, 0, 0), p += kHidden;                 // gamma
+        add(p, kHidden, 0, 0), p += kHidden;                 // beta
+        add(p, kHidden, 2, h * 32), p += kHidden;            // moving_mean
+        add(p, kHidden, 3, h * 32 + 16), p += kHidden;       // moving_variance
+        add(p, (size_t)kHidden * m->head_odim[h], 0, 0), p += (size_t)kHidden * m->head_odim[h];
+        add(p, m->head_odim[h], 0, 0);
+    }
+    t->nseg = (int)segs.size();
+    const size_t nact = (size_t)max_batch * (m->n_blocks + 1) * m->cfg.patch_size * C;
+    hipError_t e = hipMalloc((void **)&t->d_acts, nact * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_pre, (size_t)max_batch * kPS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_dpre, (size_t)max_batch * kPS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_dxh, (size_t)max_batch * kPS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_grad, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_vel, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_bnstat, kMaxHeads * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_sumsq, segs.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_scratch_out, (size_t)max_batch * m->out_dim * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Segment));
+    if (e == hipSuccess) e = hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(t->d_vel, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(t->d_grad, 0, m->n_params * sizeof(float));
+    if (e != hipSuccess) {
+        smh_trainer_destroy(t);
+        return smh::set_error(SMH_E_HIP, "smh_trainer_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return SMH_OK;
+}
+
+extern "C" void smh_trainer_destroy(smh_trainer *t) {
+    if (!t) return;
+    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_bnstat, t->d_sumsq, t->d_scratch_out})
+        (void)hipFree(p);
+    (void)hipFree(t->d_segs);
+    delete t;
+}
+
+extern "C" float *smh_trainer_grad_ptr(smh_trainer *t) { return t ? t->d_grad : nullptr; }
+
+extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
+                                  const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream) {
+    SMH_REQUIRE(t && d_x && d_y && d_losses, "smh_train_step_f32: null argument");
+    SMH_REQUIRE(N >= 1 && N <= t->max_batch, "smh_train_step_f32: batch %d outside [1, %d]", N, t->max_batch);
+    smh_model *m = t->m;
+    hipStream_t st = (hipStream_t)stream;
+    SMH_CHECK_HIP(hipMemsetAsync(t->d_grad, 0, m->n_params * sizeof(float), st));
+    TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre};
+    int rc = launch_forward(m, d_x, N, t->d_scratch_out, nullptr, &tio, st);
+    if (rc) return rc;
+    const Offsets off = offsets(m);
+    HeadsArgs ha;
+    ha.N = N, ha.D = m->D, ha.NH = m->NH, ha.n_classes = m->cfg.n_classes, ha.n_heads = m->n_heads, ha.out_dim = m->out_dim;
+    for (int i = 0; i < kMaxHeads; ++i) {
+        ha.head_odim[i] = m->head_odim[i], ha.head_sigmoid[i] = m->head_sigmoid[i];
+        ha.goff_head[i] = off.head[i];
+    }
+    for (int i = 0; i <= kMaxHeads; ++i) ha.lw[i] = 1.0f;
+    if (h_loss_weights)
+        for (int i = 0; i <= m->n_heads; ++i) ha.lw[i] = h_loss_weights[i];
+    ha.goff_c3b = off.c3_b;
+    hipLaunchKernelGGL(heads_train_kernel, dim3(1), dim3(1024), 0, st, ha, t->d_pre, d_y, m->d_hp, d_drop_heads, t->d_dpre,
+                       t->d_dxh, t->d_grad, t->d_bnstat, d_losses);
+    rc = smh::launch_status("heads_train_kernel");
+    if (rc) return rc;
+    BwdArgs ba;
+    ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
+    ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
+    const int RP = kBG * ba.T;
+    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 3 * C * C + C * C + C + 2 * RP + kBG * kPS);
+    SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel", ba.T);
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tcn_backward_kernel, dim3((N + kBG - 1) / kBG), dim3(kBThreads), lds, st, ba, d_x, m->d_flat,
+                       t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad);
+    return smh::launch_status("tcn_backward_kernel");
+}
+
+extern "C" int smh_trainer_apply_sgd_f32(smh_trainer *t, float lr, float momentum, float clipnorm, float grad_scale,
+                                         void *stream) {
+    SMH_REQUIRE(t, "smh_trainer_apply_sgd_f32: null trainer");
+    smh_model *m = t->m;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_sumsq_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, m->d_flat, t->d_grad, grad_scale,
+                       t->d_sumsq);
+    int rc = smh::launch_status("seg_sumsq_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_sgd_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, m->d_flat, t->d_grad, t->d_vel, t->d_sumsq,
+                       t->d_bnstat, lr, momentum, clipnorm);
+    rc = smh::launch_status("seg_sgd_kernel");
+    if (rc) return rc;
+    return repack(m, st);
+}

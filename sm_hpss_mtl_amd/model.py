@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .training import TrainingMixin
 
 
 def head_spec(n_classes: int):
@@ -49,7 +50,7 @@ def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_
     return spec
 
 
-class B3MTL:
+class B3MTL(TrainingMixin):
     """`model` object of get_Lemaire_MTL_model.  Inference runs entirely in libsmh (HIP)."""
 
     def __init__(self, n_feat=240, patch_size=68, n_classes=3, TR_STEPS=1, loss_weights=None, seed=None,
@@ -76,9 +77,15 @@ class B3MTL:
             else:
                 self.weights[name] = np.full(shape, float(fan_in), np.float32)
         assert self.count_params() == self.lib.smh_model_num_params(self._h)
-        self._dirty = True
+        self._dirty = True          # host copy newer than the device master
+        self._device_newer = False  # device master newer than the host copy (after optimiser steps)
+        self._init_training_state()
 
     def __del__(self):
+        t = getattr(self, "_trainer", None)
+        if t:
+            self.lib.smh_trainer_destroy(t)
+            self._trainer = None
         h = getattr(self, "_h", None)
         if h:
             self.lib.smh_model_destroy(h)
@@ -97,8 +104,26 @@ class B3MTL:
     def count_params(self):
         return int(sum(int(np.prod(s)) for _, s, _, _ in self._spec))
 
+    def _pull_weights(self):
+        if self._device_newer:
+            flat = np.empty(self.count_params(), np.float32)
+            _lib.check(self.lib.smh_model_get_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "smh_model_get_weights")
+            o = 0
+            for name, shape, _, _ in self._spec:
+                n = int(np.prod(shape))
+                self.weights[name] = flat[o:o + n].reshape(shape).copy()
+                o += n
+            self._device_newer = False
+
     def get_weights(self):
+        self._pull_weights()
         return [self.weights[n].copy() for n, _, _, _ in self._spec]
+
+    def get_weights_dict(self):
+        self._pull_weights()
+        return self.weights
 
     def set_weights(self, arrays):
         arrays = list(arrays)
@@ -110,11 +135,13 @@ class B3MTL:
                 raise ValueError("set_weights: %s expects shape %s, got %s" % (name, shape, a.shape))
             self.weights[name] = a.copy()
         self._dirty = True
+        self._device_newer = False
 
     def set_weights_dict(self, d):
         self.set_weights([d[n] for n, _, _, _ in self._spec])
 
     def save_weights(self, path):
+        self._pull_weights()
         np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **{k.replace("/", "__"): v for k, v in self.weights.items()})
 
     def load_weights(self, path):

@@ -1,0 +1,110 @@
+"""GPU: the HIP training step (forward-train, losses, backward, SGD) against the numpy oracle, which is itself
+pinned against torch autograd on the CPU (tests/test_oracle_train.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import b3_mtl, b3_mtl_train as tr
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(ncls, N, W=68, seed=0):
+    rng = np.random.default_rng(seed)
+    w = b3_mtl.init_weights(seed=3, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+    x = rng.standard_normal((N, W, 240)).astype(np.float32)
+    heads = b3_mtl.head_spec(ncls)
+    y = {n: ((rng.random((N, od)) > 0.5).astype(np.float32) if act == "sigmoid" else rng.random((N, od)).astype(np.float32))
+         for n, od, act in heads}
+    y["3C"] = np.eye(ncls, dtype=np.float32)[rng.integers(0, ncls, N)]
+    drop_tcn = ((rng.random((N, 24, 32)) > 0.2) / 0.8).astype(np.float32)
+    drop_heads = ((rng.random((N, len(heads), 16)) > 0.4) / 0.6).astype(np.float32)
+    return w, x, y, drop_tcn, drop_heads
+
+
+def _flat_to_dict(model, flat):
+    out, o = {}, 0
+    for name, shape, _, _ in model._spec:
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].reshape(shape)
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("ncls,N", [(3, 6), (5, 5), (3, 1)])
+def test_gradients_and_losses_vs_oracle(ncls, N):
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N)
+    lw = {"S": 0.7, "R": 1.3}
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls, loss_weights=lw)
+    m.set_weights_dict(w)
+    heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
+    got = m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda(),
+                           apply=False)
+    ref = tr.forward_backward(x, y, w, ncls, drop_tcn, {h: drop_heads[:, i] for i, h in enumerate(heads)}, lw)
+    # losses: [total, per-output..., acc]
+    assert abs(got[0] - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"]))
+    for i, name in enumerate(heads + ["3C"]):
+        assert abs(got[1 + i] - ref["losses"][name]) < 2e-4 * max(1.0, abs(ref["losses"][name])), name
+    assert abs(got[-1] - ref["acc"]) < 1e-6
+    torch.cuda.synchronize()
+    g = _flat_to_dict(m, m._grad_tensor().cpu().numpy())
+    for name, gref in ref["grads"].items():
+        if name.endswith(tr.TRAINABLE_SKIP):
+            continue
+        gg = g[name].astype(np.float64)
+        if name.endswith("/dense/kernel"):
+            gg = gg + 2 * tr.L2 * w[name]  # the l2 term is added at apply time on the device
+        scale = max(np.abs(gref).max(), 1e-6)
+        assert np.abs(gg - gref).max() <= 2e-3 * scale + 1e-6, (name, np.abs(gg - gref).max(), scale)
+
+
+def test_sgd_step_matches_oracle():
+    from sm_hpss_mtl_amd.model import B3MTL
+    ncls, N = 3, 8
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=5)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls, TR_STEPS=10)
+    m.set_weights_dict(w)
+    heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
+    wd, vel = {k: v.astype(np.float64) for k, v in w.items()}, {}
+    for step in range(2):
+        m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda())
+        ref = tr.forward_backward(x, y, wd, ncls, drop_tcn, {h: drop_heads[:, i] for i, h in enumerate(heads)})
+        lr = tr.exponential_decay(step, 0.002, 30, 0.1)
+        assert abs(m.learning_rate(step) - lr) < 1e-12
+        wd, vel = tr.sgd_step(wd, ref["grads"], vel, ref["bn_batch"], lr)
+    got = m.get_weights_dict()
+    for k, v in wd.items():
+        delta = np.abs(v - w[k]).max()  # how far the oracle moved this tensor
+        assert np.abs(got[k] - v).max() <= 2e-3 * max(delta, 1e-7) + 1e-7, k
+
+
+def test_fit_evaluate_surface(tmp_path):
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
+    rng = np.random.default_rng(0)
+    model, lr = get_Lemaire_MTL_model(TR_STEPS=4, N_MELS=240, n_classes=3, patch_size=68, seed=1)
+    # a separable toy problem: class decided by the sign pattern of the mean feature
+    def batch(n=48):
+        cls = rng.integers(0, 3, n)
+        x = rng.standard_normal((n, 68, 240)).astype(np.float32) * 0.3 + (cls[:, None, None] - 1.0) * 0.8
+        y = {"S": (cls == 1).astype(np.float32)[:, None], "M": (cls == 0).astype(np.float32)[:, None],
+             "R": np.stack([(cls != 1), (cls != 0)], 1).astype(np.float32), "3C": np.eye(3, dtype=np.float32)[cls]}
+        return x, y
+    def gen():
+        while True:
+            yield batch()
+    vx, vy = batch(96)
+    before = model.evaluate(vx, vy)
+    assert len(before) == len(model.metrics_names) == 6
+    hist = model.fit(gen(), steps_per_epoch=4, epochs=6, validation_data=(vx, vy), verbose=0,
+                     csv_log=str(tmp_path / "log.csv"), checkpoint_path=str(tmp_path / "best"),
+                     early_stopping=dict(monitor="val_loss", min_delta=0.01, patience=5, restore_best_weights=True))
+    after = model.evaluate(vx, vy)
+    assert model.iterations == 24 and len(hist.history["loss"]) == 6 and "val_3C_accuracy" in hist.history
+    assert after[0] < before[0], (before, after)  # the loss went down
+    assert after[-1] >= before[-1]
+    assert (tmp_path / "log.csv").exists() and (tmp_path / "best.npz").exists()
+    # evaluate == oracle inference losses on the trained weights
+    w = model.get_weights_dict()
+    outs = b3_mtl.forward(vx, w)
+    assert abs(float(np.mean(-np.sum(vy["3C"] * np.log(np.clip(outs[-1], 1e-7, 1)), axis=1))) - after[4]) < 1e-3
