@@ -108,3 +108,28 @@ def test_weight_spec_matches_oracle_order():
         spec = weight_spec(240, W, ncls)
         assert [n for n, _, _, _ in spec] == list(w.keys())
         assert [tuple(s) for _, s, _, _ in spec] == [v.shape for v in w.values()]
+
+
+def test_label_assembly_matches_reference_rules():
+    """a15: Proposed_Work_Results.py:170-262 and 5_class_classification.py:602-671 restated literally."""
+    from sm_hpss_mtl_amd.batching import make_labels_3class, make_labels_5class
+    bs = 4
+    smr = np.array([-5, 0, 10, 20])
+    lab = make_labels_3class(bs, smr)
+    R = np.ones((3 * bs, 2))
+    R[:bs] = [1, 0]
+    R[bs:2 * bs] = [0, 1]
+    for i, d in enumerate(smr):
+        R[2 * bs + i] = [1 / np.power(10, d / 10), 1] if d >= 0 else [1, np.power(10, d / 10)]
+    assert np.allclose(lab["R"], R)
+    assert lab["S"].tolist() == [0] * bs + [1] * bs + [0] * bs     # the reference leaves S=0 on the mixtures
+    assert lab["M"].tolist() == [1] * bs + [0] * bs + [0] * bs
+    assert lab["3C"].argmax(1).tolist() == [0] * bs + [1] * bs + [2] * bs
+    l5 = make_labels_5class(bs, smr, -smr)
+    assert l5["S"].tolist() == [0] * bs + [1] * bs + [1] * bs + [0] * bs + [1] * bs
+    assert l5["M"].tolist() == [1] * bs + [0] * bs + [1] * bs + [0] * bs + [0] * bs
+    assert l5["N"].tolist() == [0] * bs + [0] * bs + [0] * bs + [1] * bs + [1] * bs
+    assert l5["R"].shape == (5 * bs, 3) and np.allclose(l5["R"][3 * bs], [0, 0, 1])
+    assert np.allclose(l5["R"][2 * bs + 2], [0.1, 1, 0]) and np.allclose(l5["R"][4 * bs], [0, 1, 10 ** 0.5][:3] if False else l5["R"][4 * bs])
+    d = -smr[0]  # +5 dB speech-to-noise
+    assert np.allclose(l5["R"][4 * bs], [0, 1 / np.power(10, d / 10), 1])
