@@ -206,9 +206,11 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
     float *rowm = B1 + C;                   // per row: m
     float *rowmx = rowm + RP;               // per row: max
     float *dps = rowmx + RP;                // [kBG][kPS] d loss / d pre
+    int *rowt = reinterpret_cast<int *>(dps + kBG * kPS);  // per row: frame index inside its patch
     const int tid = threadIdx.x, nt = blockDim.x;
 
     for (int i = tid; i < g_here * kPS; i += nt) dps[i] = dpre[(size_t)n0 * kPS + i];
+    for (int i = tid; i < RP; i += nt) rowt[i] = i % T;
     __syncthreads();
     // ---- Dense-on-trunk backward: G = relu'(x) * (dpre @ Wh^T);  dWh += flat^T dpre --------------------
     for (int i = tid; i < rows * C; i += nt) {
@@ -251,7 +253,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
         // recompute u = conv_d(x) + b1
         for (int i = tid; i < rows * C; i += nt) {
             const int R = i / C, co = i - R * C;
-            const int t = R % T;
+            const int t = rowt[R];
             float acc = B1[co];
             for (int tap = 0; tap < 3; ++tap) {
                 const int off = (tap - 1) * d;
@@ -319,7 +321,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
             const int off = (tap - 1) * d;
             float acc = 0.f, accb = 0.f;
             for (int R = 0; R < rows; ++R) {
-                const int t = R % T;
+                const int t = rowt[R];
                 const float duv = U[R * kBS + co];
                 accb += duv;
                 if (t + off >= 0 && t + off < T) acc = fmaf(Xs[(R + off) * kBS + c], duv, acc);
@@ -331,7 +333,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
         // g[R][c] += sum_tap sum_co du[R - off][co] W1[tap][c][co]
         for (int i = tid; i < rows * C; i += nt) {
             const int R = i / C, c = i - R * C;
-            const int t = R % T;
+            const int t = rowt[R];
             float acc = G[R * kBS + c];
             for (int tap = 0; tap < 3; ++tap) {
                 const int off = (tap - 1) * d;
@@ -505,7 +507,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
     const int RP = kBG * ba.T;
-    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 3 * C * C + C * C + C + 2 * RP + kBG * kPS);
+    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 3 * C * C + C * C + C + 3 * RP + kBG * kPS);
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel", ba.T);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tcn_backward_kernel, dim3((N + kBG - 1) / kBG), dim3(kBThreads), lds, st, ba, d_x, m->d_flat,
