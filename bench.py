@@ -161,14 +161,30 @@ def main():
     tf = FLOPS_MODEL * B / (ms["model"] * 1e-3) / 1e12
     kernels["model"] = {"ms": round(ms["model"], 4), "bound": "mfma", "achieved_TFLOPs": round(tf, 2),
                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    # measured HBM traffic per launch from the committed rocprofv3 PMC passes (tools/gpu/collect_profiles.sh)
+    pmc = {}
+    try:
+        import glob
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if fs:
+            pmc = json.load(open(fs[-1]))
+    except Exception:  # no profile committed yet
+        pmc = {}
+
+    def traffic(keys):
+        vals = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in keys]
+        return None if any(v is None for v in vals) else float(sum(vals))
+    for n, keys in (("stft", ["stft"]), ("median", ["median"]), ("features", ["hp_feat", "std_patch"]), ("model", ["model"])):
+        kernels[n]["pmc_hbm_bytes_per_launch_at_B1024"] = traffic(keys)
     dominant = max(names, key=lambda n: ms[n])
     if dominant == "model":
         roof = {"kernel": "tcn_trunk_kernel+heads_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic(["model"]) if B == 1024 else None}
     else:
         kn = {"stft": "stft_mag_kernel", "median": "hpss_median_kernel", "features": "hp_feat_kernel+std_patch_kernel"}[dominant]
         roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dominant]["frac"], "traffic": None}
+                "unit": "GB/s", "frac": kernels[dominant]["frac"],
+                "traffic": traffic({"stft": ["stft"], "median": ["median"], "features": ["hp_feat", "std_patch"]}[dominant]) if B == 1024 else None}
 
     if rank == 0:
         clips_total = world * B * args.steps
