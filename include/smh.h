@@ -135,6 +135,32 @@ int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samp
                      float *d_patches, void *d_work, size_t work_bytes, float *d_S, float *d_harm, float *d_perc,
                      void *stream);
 
+/* ---- 8f rank 1: load_and_preprocess_signal after the decode (lib/preprocessing.py:330-350) ------------------
+ * Batched over B clips of N samples each, resident on the device.  Floating point: the mean is accumulated in
+ * f64 in a fixed order (numpy: pairwise f32), everything else is the same f32 arithmetic as numpy.           */
+/* bytes of device workspace for smh_normalize_f32 / for the silence functions (hop = frame shift in samples) */
+size_t smh_normalize_workspace_bytes(int B, int N);
+size_t smh_silence_workspace_bytes(int B, int N, int hop);
+/* Xin -= mean(Xin); Xin /= max|Xin| per clip (preprocessing.py:332-333,348-349).  d_out may alias d_x.        */
+int smh_normalize_f32(const float *d_x, int B, int N, float *d_out, void *d_work, size_t work_bytes, void *stream);
+/* librosa.feature.rms(y=, frame_length=, hop_length=)[0] (preprocessing.py:338): center=True, reflect padding.
+ * d_y (B, N) -> d_energy (B, nFrames); returns nFrames = 1 + (N + 2*(frame_length/2) - frame_length)/hop.      */
+int smh_rms_f32(const float *d_y, int B, int N, int frame_length, int hop, float *d_energy, void *stream);
+/* tools.removeSilence(Xin, nSamples, energy, nFrames, fs, Tw, Ts, alpha, beta) (lib/cython_impl/tools.pyx:42-134),
+ * integer-exact given the energies: float threshold alpha*max(energy), scipy medfilt(marker, 5) with zero padding,
+ * the literal run loop, removal only when at least two runs exceed beta seconds.  d_out (B, N) keeps the input
+ * length: retained samples first, then the reference's tail of 1.0 (unchanged copy when nothing is removed).
+ * Optional outputs (null to skip): d_sample_marker (B, N) u8, d_frame_marker (B, nFrames) i32, d_n_keep (B) i32 =
+ * number of retained samples (N when nothing was removed).  d_out must not alias d_x.                         */
+int smh_remove_silence_f32(const float *d_x, int B, int N, const float *d_energy, int nFrames, int fs, int Tw, int Ts,
+                           double alpha, double beta, float *d_out, unsigned char *d_sample_marker, int *d_frame_marker,
+                           int *d_n_keep, void *d_work, size_t work_bytes, void *stream);
+/* preprocessing.py:332-349 in one call: normalise, rms(frameSize, frameShift), removeSilence (alpha=0.025,
+ * beta=0.075), normalise again (tail of ones included, as in the reference).  The "< 0.1 s: duplicate" rule of
+ * :343-346 depends on N alone and stays with the host caller.                                                  */
+int smh_preprocess_signal_f32(const float *d_x, int B, int N, int fs, int Tw, int Ts, float *d_out, int *d_n_keep,
+                              void *d_work, size_t work_bytes, void *stream);
+
 /* ---- a10-a12: B3_MTL = get_Lemaire_MTL_model (lib/proposed_architectures.py:85-170, 25-80) ---- */
 typedef struct smh_model_cfg {
     int32_t n_feat;     /* N_MELS argument = input_shape[1]: 240                       */

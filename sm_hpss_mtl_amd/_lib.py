@@ -51,6 +51,13 @@ SIGNATURES = {
     "smh_features_ex_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
     "smh_frontend_workspace_bytes": (_sz, [_vp, _i, _i]),
     "smh_frontend_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _fp, _fp, _fp, _vp]),
+    "smh_normalize_workspace_bytes": (_sz, [_i, _i]),
+    "smh_silence_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smh_normalize_f32": (_i, [_fp, _i, _i, _fp, _vp, _sz, _vp]),
+    "smh_rms_f32": (_i, [_fp, _i, _i, _i, _i, _fp, _vp]),
+    "smh_remove_silence_f32": (_i, [_fp, _i, _i, _fp, _i, _i, _i, _i, C.c_double, C.c_double, _fp, _vp, _vp, _vp, _vp,
+                                    _sz, _vp]),
+    "smh_preprocess_signal_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _sz, _vp]),
     "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "smh_model_destroy": (None, [_vp]),
     "smh_model_num_params": (_sz, [_vp]),

@@ -2,8 +2,9 @@
 
 `extract_patches` (tools.pyx:21-38) is on the hot path and runs as a HIP gather through the C ABI
 (`smh_extract_patches_f32`); it returns float64 (nP, F, W) exactly like the Cython function.
-`removeSilence` is SURVEY 8(f) rank 1 ("next"); `scale_data` / `get_data_statistics` are out of scope
-(off by default in the reference: frame_level_scaling False, skewness_vector None).
+`removeSilence` (tools.pyx:42-134) runs through `smh_remove_silence_f32`; `scale_data` /
+`get_data_statistics` are out of scope (off by default in the reference: frame_level_scaling False,
+skewness_vector None).
 """
 from __future__ import annotations
 
@@ -39,8 +40,31 @@ def extract_patches(FV, shape, patch_size, patch_shift):
     return out.cpu().numpy().astype(np.float64)
 
 
-def removeSilence(*args, **kwargs):
-    raise NotImplementedError("tools.removeSilence is a 'next' row (SURVEY 8f rank 1), not built in this round")
+def removeSilence(Xin, nSamples, energy, nFrames, fs, Tw, Ts, alpha=0.025, beta=0.075):
+    """tools.pyx:42-134 -> (Xin_silrem, sample_silMarker, frame_silMarker, totalSilDuration) with the reference's
+    dtypes (float32 / int64 / int64 / int) and its quirks: nothing is removed unless two runs qualify, the output
+    keeps the input length with a tail of 1.0, and with fewer than two runs `Xin` itself is returned."""
+    from ... import silence as _sil
+    Xin_np = np.asarray(Xin)
+    energy_np = np.asarray(energy)
+    if Xin_np.ndim != 1 or len(Xin_np) != nSamples:
+        raise ValueError("removeSilence: Xin has shape %s, nSamples=%r" % (Xin_np.shape, nSamples))
+    if energy_np.ndim != 1 or len(energy_np) != nFrames:
+        raise ValueError("removeSilence: energy has shape %s, nFrames=%r" % (energy_np.shape, nFrames))
+    dx = torch.from_numpy(np.ascontiguousarray(Xin_np, dtype=np.float32)).cuda()
+    de = torch.from_numpy(np.ascontiguousarray(energy_np, dtype=np.float32)).cuda()
+    out, n_keep, sm, fm = _sil.remove_silence(dx, de, fs, Tw, Ts, alpha, beta, markers=True)
+    sample_silMarker = sm[0].cpu().numpy().astype(np.int64)
+    frame_silMarker = fm[0].cpu().numpy().astype(np.int64)
+    # the removed runs are the zero stretches of the sample marker (consecutive runs never touch)
+    d = np.diff(np.concatenate([[1], sample_silMarker, [1]]))
+    starts, ends = np.where(d == -1)[0], np.where(d == 1)[0]
+    totalSilDuration = 0
+    for k, l in zip(starts, ends):
+        totalSilDuration = int(totalSilDuration + (l - k) / fs)  # `cdef int` accumulator, tools.pyx:85,121
+    if len(starts) > 1:
+        return out[0].cpu().numpy(), sample_silMarker, frame_silMarker, totalSilDuration
+    return Xin, sample_silMarker, frame_silMarker, totalSilDuration
 
 
 def scale_data(*args, **kwargs):

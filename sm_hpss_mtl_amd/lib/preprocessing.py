@@ -8,14 +8,13 @@ return types as the reference, computed by the HIP library.
 plus the batched, device-resident fast path the reference does not have:
   featuregram_batch / feature_patches_batch.
 
-Per-file functions are thin wrappers: one clip is a batch of one.  Audio loading, silence removal
-(`load_and_preprocess_signal`) are 'next' rows: `get_featuregram` reads .wav/.npy
-files, applies the reference's normalisation and mixing, and bypasses silence removal (it warns once).
+Per-file functions are thin wrappers: one clip is a batch of one.  `load_and_preprocess_signal` (SURVEY 8f
+rank 1) decodes .wav/.npy on the host and runs normalise -> rms -> removeSilence -> normalise on the device
+(`smh_preprocess_signal_f32`); `preprocess_signal_batch` is the device-resident form for equal-length clips.
 """
 from __future__ import annotations
 
 import os
-import warnings
 
 import numpy as np
 import torch
@@ -62,9 +61,6 @@ def mix_signals(Xin_sp, Xin_mu, target_dB):
     return normalize_signal(Xin_mix)
 
 
-_warned_silence = False
-
-
 def _read_audio(fName, sr=16000):
     """Minimal loader for the 'next' row: .npy (float array already at 16 kHz) or PCM/float .wav."""
     if fName.endswith(".npy"):
@@ -86,18 +82,24 @@ def _read_audio(fName, sr=16000):
     return x, sr
 
 
+def preprocess_signal_batch(Xin, fs, Tw, Ts):
+    """preprocessing.py:332-349 for a float32 CUDA tensor (B, N) of equal-length clips, device resident.
+    Returns (Xin_silrem (B, N), n_keep (B,)): like the reference the output keeps the input length, retained
+    samples first, then the normalised image of its tail of ones."""
+    from .. import silence as _sil
+    return _sil.preprocess_signal(Xin, fs, Tw, Ts)
+
+
 def load_and_preprocess_signal(fName, Tw, Ts):
-    """preprocessing.py:330-350 without the silence-removal step."""
-    global _warned_silence
-    if not _warned_silence:
-        warnings.warn("load_and_preprocess_signal: silence removal is not built yet (next row); bypassed")
-        _warned_silence = True
+    """preprocessing.py:330-350 -> (Xin_silrem float32, fs)."""
     Xin, fs = _read_audio(fName)
-    Xin = normalize_signal(Xin)
-    if len(Xin) / fs < 0.1:
-        while len(Xin) / fs < 0.1:
-            Xin = np.append(Xin, Xin)
-    return normalize_signal(Xin), fs
+    dx = torch.from_numpy(np.ascontiguousarray(Xin, dtype=np.float32)).cuda()
+    out, _ = preprocess_signal_batch(dx[None], fs, Tw, Ts)
+    Xin_silrem = out[0].cpu().numpy()
+    if len(Xin_silrem) / fs < 0.1:  # :343-346; duplication keeps mean and max, so the order with :348-349 is free
+        while len(Xin_silrem) / fs < 0.1:
+            Xin_silrem = np.append(Xin_silrem, Xin_silrem)
+    return Xin_silrem, fs
 
 
 # ---- featuregram ------------------------------------------------------------------------------------------

@@ -29,3 +29,27 @@ def synth_clips(batch: int, seed: int = 0, n_samples: int = 16000, fs: int = 160
         x = x / np.max(np.abs(x))
         out[i] = x.astype(np.float32)
     return out
+
+
+# (n_samples, [(start_s, end_s) of near-silent stretches]) -- the cases of tests/golden/silence_golden.npz
+SILENCE_CASES = (
+    (32000, ((0.2, 0.5), (1.0, 1.3))),              # two runs -> removal
+    (32000, ((0.4, 0.9),)),                          # one run -> untouched
+    (32000, ()),                                     # no silence
+    (32000, ((0.0, 0.3), (0.8, 1.1), (1.7, 2.0))),   # silence at both ends
+    (32000, ((0.1, 0.15), (0.5, 0.9), (1.2, 1.26))), # short stretches below beta
+    (64000, ((0.2, 1.6), (2.0, 3.3))),               # runs longer than one second (integer duration accumulator)
+    (16000, ((0.3, 0.45), (0.6, 0.8))),              # the bench clip length
+)
+
+
+def gappy_clip(case: int, fs: int = 16000) -> np.ndarray:
+    """Seeded noise with near-silent stretches (float32, not normalised): input of the silence-removal tests."""
+    n, gaps = SILENCE_CASES[case]
+    rng = np.random.default_rng(1000 + case)
+    x = (0.3 * rng.standard_normal(n)).astype(np.float32)
+    env = (0.75 + 0.5 * ((np.arange(n) % 4000) / 4000.0)).astype(np.float32)  # sawtooth: exactly reproducible
+    x *= env
+    for a, b in gaps:
+        x[int(a * fs):int(b * fs)] *= np.float32(1e-4)
+    return x

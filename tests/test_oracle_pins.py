@@ -139,3 +139,73 @@ def test_b3mtl_dilated_conv_matches_torch():
         ref = torch.nn.functional.conv1d(torch.from_numpy(x).permute(0, 2, 1), torch.from_numpy(k).permute(2, 1, 0),
                                          torch.from_numpy(b), padding=d, dilation=d).permute(0, 2, 1).numpy()
         np.testing.assert_allclose(b3_mtl.conv1d_same(x, k, b, d), ref, atol=1e-5)
+
+
+def _ref_tools():
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not any(f.startswith("tools") and f.endswith(".so") for f in (os.listdir(ref_dir) if os.path.isdir(ref_dir) else [])):
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, ref_dir)
+    try:
+        tools = importlib.import_module("tools")
+    finally:
+        sys.path.remove(ref_dir)
+    ss = pytest.importorskip("scipy.signal")
+    # modern scipy.signal.medfilt keeps int64 where the 2021 one promoted to float64 (tools.pyx:98 expects
+    # double): rebind the module global, the reference source itself is untouched
+    tools.medfilt = lambda v, k: ss.medfilt(np.asarray(v, float), k)
+    return tools
+
+
+def _silence_case(c):
+    from oracle import silence as sil
+    from sm_hpss_mtl_amd.synth import gappy_clip
+    x = sil.normalize_signal(gappy_clip(c))
+    return x, sil.rms(x, 400, 160)
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_remove_silence_vs_compiled_reference(case):
+    from oracle import silence as sil
+    from sm_hpss_mtl_amd.synth import SILENCE_CASES
+    tools = _ref_tools()
+    gaps = SILENCE_CASES[case][1]
+    x, energy = _silence_case(case)
+    assert energy.shape == (1 + len(x) // 160,) and energy.dtype == np.float32
+    ref_out, ref_sm, ref_fm, ref_tot = tools.removeSilence(x, len(x), energy, len(energy), 16000, 25, 10)
+    out, sm, fm, tot = sil.remove_silence(x, energy, 16000, 25, 10)
+    assert tot == ref_tot
+    assert np.array_equal(fm, ref_fm) and np.array_equal(sm, ref_sm)
+    assert out.dtype == ref_out.dtype and np.array_equal(out, ref_out)
+    if out is not x:  # >= 2 qualifying runs: the reference's tail of ones
+        n_keep = int(sm.sum())
+        assert n_keep < len(x) and np.all(out[n_keep:] == 1.0)
+    else:  # 0 or 1 qualifying runs: input returned untouched, even though sample_marker may hold zeros
+        assert sum(b - a > 0.1 for a, b in gaps) < 2
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_remove_silence_vs_golden(case):
+    """The committed outputs of the compiled reference (tests/golden/make_silence_golden.py)."""
+    import hashlib
+    from oracle import silence as sil
+    g = np.load(os.path.join(ROOT, "tests", "golden", "silence_golden.npz"))
+    x, energy = _silence_case(case)
+    assert hashlib.sha256(x.tobytes()).digest() == g["c%d_x_sha" % case].tobytes()
+    assert np.array_equal(energy, g["c%d_energy" % case])
+    out, sm, fm, tot = sil.remove_silence(x, energy, 16000, 25, 10)
+    n, n_keep, untouched, ref_tot = g["c%d_meta" % case]
+    assert (len(x), int(sm.sum()), int(out is x), tot) == (n, n_keep, untouched, ref_tot)
+    assert np.array_equal(fm, g["c%d_frame_marker" % case])
+    assert np.array_equal(np.packbits(sm.astype(np.uint8)), g["c%d_sample_marker" % case])
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == g["c%d_out_sha" % case].tobytes()
+
+
+def test_rms_closed_form():
+    from oracle import silence as sil
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(1000).astype(np.float32)
+    e = sil.rms(y, 400, 160)
+    yp = np.concatenate([y[200:0:-1], y, y[-2:-202:-1]])  # numpy 'reflect': no edge repeat
+    for t in (0, 3, len(e) - 1):
+        assert abs(e[t] - np.sqrt(np.mean(yp[t * 160:t * 160 + 400].astype(np.float64) ** 2))) < 1e-6

@@ -1,0 +1,196 @@
+"""GPU parity tests of the step in front of the hot path: normalise, rms, removeSilence.
+
+Bars: the silence decision is integer work -> bit-exact markers / compaction given the same float32 energies (the
+committed outputs of the compiled reference, tests/golden/silence_golden.npz, and the numpy oracle); the two
+floating-point pieces (mean / rms accumulate in another order than numpy) carry stated tolerances."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import silence as osil
+from sm_hpss_mtl_amd.synth import SILENCE_CASES, gappy_clip
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCASE = len(SILENCE_CASES)
+
+
+@pytest.fixture(scope="module")
+def sil():
+    from sm_hpss_mtl_amd import silence
+    return silence
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "silence_golden.npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def test_normalize_vs_oracle(sil):
+    x = np.stack([gappy_clip(c) for c in (0, 1, 2, 3)]) + np.float32(0.05)  # same length, non-zero mean
+    ref = np.stack([osil.normalize_signal(r) for r in x])
+    out = host(sil.normalize(dev(x)))
+    assert out.dtype == np.float32 and out.shape == x.shape
+    assert np.max(np.abs(out - ref)) <= 2e-7  # mean: f64 ordered sum here, pairwise f32 in numpy; |out| <= 1
+    assert np.all(np.max(np.abs(out), axis=1) == 1.0)  # the peak sample divides to exactly one
+    d = dev(x)
+    assert sil.normalize(d, out=d) is d  # in place
+    assert np.array_equal(host(d), out)
+    # multi-chunk clip (> 8192 samples per workgroup) with a ragged end, batch of one given as 1-D
+    y = np.random.default_rng(5).standard_normal(100003).astype(np.float32)
+    assert np.max(np.abs(host(sil.normalize(dev(y)))[0] - osil.normalize_signal(y))) <= 2e-7
+
+
+@pytest.mark.parametrize("n,fl,hop", [(32000, 400, 160), (16000, 400, 160), (1000, 400, 160), (5001, 512, 128)])
+def test_rms_vs_oracle(sil, n, fl, hop):
+    rng = np.random.default_rng(n)
+    y = rng.standard_normal((3, n)).astype(np.float32)
+    e = host(sil.rms(dev(y), fl, hop))
+    assert e.shape == (3, 1 + n // hop)  # librosa frame count (integer contract)
+    for i in range(3):
+        ref = osil.rms(y[i], fl, hop)
+        assert np.max(np.abs(e[i] - ref) / ref) <= 1e-6  # f32 sum of 400 squares in another order
+
+
+@pytest.mark.parametrize("case", range(NCASE))
+def test_remove_silence_bit_exact_vs_reference_golden(sil, golden, case):
+    x = osil.normalize_signal(gappy_clip(case))
+    assert hashlib.sha256(x.tobytes()).digest() == golden["c%d_x_sha" % case].tobytes()
+    energy = golden["c%d_energy" % case]
+    out, n_keep, sm, fm = sil.remove_silence(dev(x), dev(energy), 16000, 25, 10, markers=True)
+    out, n_keep, sm, fm = host(out)[0], int(host(n_keep)[0]), host(sm)[0], host(fm)[0]
+    n, ref_keep, untouched, _ = golden["c%d_meta" % case]
+    assert np.array_equal(fm, golden["c%d_frame_marker" % case])
+    assert np.array_equal(np.packbits(sm), golden["c%d_sample_marker" % case])
+    assert n_keep == (n if untouched else ref_keep)
+    assert hashlib.sha256(out.tobytes()).digest() == golden["c%d_out_sha" % case].tobytes()
+    o_ref, sm_ref, fm_ref, _ = osil.remove_silence(x, energy, 16000, 25, 10)
+    assert np.array_equal(out, o_ref) and np.array_equal(sm, sm_ref) and np.array_equal(fm, fm_ref)
+
+
+def test_remove_silence_batched_matches_per_clip(sil):
+    cases = [c for c in range(NCASE) if SILENCE_CASES[c][0] == 32000]
+    x = np.stack([osil.normalize_signal(gappy_clip(c)) for c in cases])
+    e = np.stack([osil.rms(r, 400, 160) for r in x])
+    out, n_keep = sil.remove_silence(dev(x), dev(e), 16000, 25, 10)
+    out, n_keep = host(out), host(n_keep)
+    for i in range(len(cases)):
+        xi = x[i]
+        o_ref, sm_ref, _, _ = osil.remove_silence(xi, e[i], 16000, 25, 10)
+        assert np.array_equal(out[i], o_ref)
+        assert n_keep[i] == (len(o_ref) if o_ref is xi else int(sm_ref.sum()))
+
+
+def test_tools_removeSilence_signature_and_quirks(sil):
+    """The Cython function's own call form (lib/preprocessing.py:339) and return tuple."""
+    from sm_hpss_mtl_amd.lib.cython_impl import tools
+    for case in (0, 1, 5):
+        x = osil.normalize_signal(gappy_clip(case))
+        e = osil.rms(x, 400, 160)
+        o, sm, fm, tot = tools.removeSilence(x, len(x), e, len(e), 16000, 25, 10)
+        o_ref, sm_ref, fm_ref, tot_ref = osil.remove_silence(x, e, 16000, 25, 10)
+        assert (o is x) == (o_ref is x)  # fewer than two runs: the input object itself comes back
+        assert o.dtype == np.float32 and sm.dtype == np.int64 and fm.dtype == np.int64
+        assert np.array_equal(o, o_ref) and np.array_equal(sm, sm_ref) and np.array_equal(fm, fm_ref)
+        assert tot == tot_ref and isinstance(tot, int)
+    with pytest.raises(ValueError):
+        tools.removeSilence(x, len(x) - 1, e, len(e), 16000, 25, 10)
+
+
+@pytest.mark.parametrize("multipass", [False, True])
+@pytest.mark.parametrize("case", range(NCASE))
+def test_preprocess_signal_vs_oracle(sil, case, multipass, monkeypatch):
+    """Both device paths: the clip-in-LDS kernel (N <= 36000) and the general multi-pass one."""
+    if multipass:
+        monkeypatch.setenv("SMH_SILENCE_MULTIPASS", "1")
+    raw = gappy_clip(case) + np.float32(0.01)
+    ref = osil.load_and_preprocess_from_samples(raw)
+    out, n_keep = sil.preprocess_signal(dev(raw), 16000, 25, 10)
+    out = host(out)[0]
+    assert out.shape == ref.shape
+    # same silence decision (the test signals keep their energies far from the threshold), then two normalisations
+    assert np.max(np.abs(out - ref)) <= 1e-6
+    xn = osil.normalize_signal(raw)
+    o_ref, sm_ref, _, _ = osil.remove_silence(xn, osil.rms(xn, 400, 160), 16000, 25, 10)
+    assert int(host(n_keep)[0]) == (len(raw) if o_ref is xn else int(sm_ref.sum()))
+
+
+def test_preprocess_signal_long_and_odd_lengths(sil):
+    """A 7 s file (multi-pass path, several chunks per clip) and an odd length (scalar loads in the LDS kernel)."""
+    rng = np.random.default_rng(3)
+    for n in (112001, 16001, 4999):
+        raw = (0.2 * rng.standard_normal((2, n))).astype(np.float32)
+        raw[:, n // 5: n // 5 + 2500] *= 1e-4
+        raw[0, n // 2: n // 2 + 2000] *= 1e-4
+        out, n_keep = sil.preprocess_signal(dev(raw), 16000, 25, 10)
+        out, n_keep = host(out), host(n_keep)
+        if n > 5000:
+            assert n_keep[0] < n and n_keep[1] == n  # clip 0 has two runs, clip 1 only one
+        for i in range(2):
+            assert np.max(np.abs(out[i] - osil.load_and_preprocess_from_samples(raw[i]))) <= 1e-6
+            xn = osil.normalize_signal(raw[i])
+            o_ref, sm_ref, _, _ = osil.remove_silence(xn, osil.rms(xn, 400, 160), 16000, 25, 10)
+            assert n_keep[i] == (n if o_ref is xn else int(sm_ref.sum()))
+
+
+def test_load_and_preprocess_signal_file(tmp_path, sil):
+    """lib/preprocessing.py:330-350 through the reference's own function name, from a file."""
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    raw = gappy_clip(0)
+    f = str(tmp_path / "clip.npy")
+    np.save(f, raw)
+    out, fs = pp.load_and_preprocess_signal(f, 25, 10)
+    ref = osil.load_and_preprocess_from_samples(raw)
+    assert fs == 16000 and out.dtype == np.float32 and out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) <= 1e-6
+    short = raw[:700]  # < 0.1 s: duplicated until long enough (:343-346)
+    np.save(f, short)
+    out, _ = pp.load_and_preprocess_signal(f, 25, 10)
+    ref = osil.load_and_preprocess_from_samples(short)
+    assert out.shape == ref.shape == (2800,)
+    assert np.max(np.abs(out - ref)) <= 1e-6
+
+
+def test_large_batch_properties(sil):
+    """BASELINE batch (1024 one-second clips): idempotence of normalise and conservation laws of the compaction."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1024, 16000)).astype(np.float32)
+    for b in range(0, 1024, 2):  # every other clip gets two silent stretches
+        x[b, 2000:5000] *= 1e-4
+        x[b, 9000:12000] *= 1e-4
+    d = sil.normalize(dev(x))
+    out, n_keep, sm, fm = sil.remove_silence(d, sil.rms(d, 400, 160), 16000, 25, 10, markers=True)
+    torch.cuda.synchronize()
+    kept = sm.sum(dim=1, dtype=torch.int64)
+    assert torch.equal(kept[0::2], n_keep[0::2].long())  # removed clips: n_keep == retained samples
+    assert torch.all(n_keep[1::2] == 16000) and torch.equal(out[1::2], d[1::2])  # untouched clips are copies
+    assert torch.all(n_keep[0::2] < 16000 - 4000)
+    for b in (0, 510):
+        k = int(n_keep[b])
+        assert torch.equal(out[b, :k], d[b][sm[b].bool()]) and torch.all(out[b, k:] == 1.0)
+    again = sil.normalize(sil.normalize(d))
+    assert torch.max(torch.abs(again - d)) <= 1e-6
+
+
+def test_error_behaviour(sil):
+    x = dev(np.zeros((2, 1000), np.float32))
+    with pytest.raises(ValueError):
+        sil.rms(x[:, :100], 400, 160)  # reflect padding needs N > frame_length/2
+    with pytest.raises(ValueError):
+        sil.remove_silence(x, dev(np.zeros((3, 7), np.float32)), 16000, 25, 10)
+    with pytest.raises(TypeError):
+        sil.normalize(x.double())
+    e = sil.rms(dev(np.zeros((0, 1000), np.float32)), 400, 160)
+    assert e.shape == (0, 7)  # empty batch
