@@ -18,6 +18,9 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libsmh.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file additions.  smh_median_split: pure selection on finite magnitudes; without the flag every fminf/fmaxf of
+# a value loaded from LDS is preceded by a canonicalising v_max_f32 (IEEE mode), +30 % VALU in that kernel.
+EXTRA_FLAGS = {"smh_median_split.hip": ["-fno-honor-nans"]}
 
 
 def _sources():
@@ -35,7 +38,7 @@ def _compile(src: str, force: bool) -> str:
     srcp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _headers_mtime()):
         return obj
-    cmd = ["hipcc", *FLAGS, "-c", srcp, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

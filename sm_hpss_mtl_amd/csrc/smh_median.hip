@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include "smh_median_kernel.h"
+#include "smh_median_split.h"
 
 namespace smh_median {
 
@@ -122,6 +123,34 @@ int make_plan(int K, int T, int lh, int lp, Plan *p) {
     return SMH_OK;
 }
 
+// Roles of the block-split kernel: per-lane cost ~ (outputs + one block of start-up) x (VALU per output ~ W + 6);
+// pick the segment counts that minimise the longest lane within the workgroup's wave budget.
+bool make_split_roles(int K, int nt, int lh, int lp, int maxwaves, Plan *p) {
+    auto waves = [](int n, int seg) { return seg ? (n * seg + 63) / 64 : 0; };
+    long best = -1;
+    int bh = 0, bp = 0;
+    for (int nsh = lh ? 1 : 0; nsh <= (lh ? 4 : 0); ++nsh) {
+        if (lh && nsh > 1 && nt < 2 * lh * nsh) break;
+        for (int nsp = lp ? 1 : 0; nsp <= (lp ? 6 : 0); ++nsp) {
+            if (lp && nsp > 1 && K < 2 * lp * nsp) break;
+            if (waves(K, nsh) + waves(nt, nsp) > maxwaves) continue;
+            const long ch = lh ? (long)((nt + nsh - 1) / nsh + lh) * (lh + 6) : 0;
+            const long cp = lp ? (long)((K + nsp - 1) / nsp + lp) * (lp + 6) : 0;
+            const long c = ch > cp ? ch : cp;
+            if (best < 0 || c < best) best = c, bh = nsh, bp = nsp;
+        }
+    }
+    if (best < 0) return false;
+    if (const char *ev = getenv("SMH_MEDIAN_SEG")) {  // tuning override (tools/tune_median.py): "nsh,nsp"
+        int a = 0, b = 0;
+        if (sscanf(ev, "%d,%d", &a, &b) == 2 && (!lh || a >= 1) && (!lp || b >= 1) &&
+            waves(K, lh ? a : 0) + waves(nt, lp ? b : 0) <= maxwaves)
+            bh = lh ? a : 0, bp = lp ? b : 0;
+    }
+    p->nsh = bh, p->nsp = bp, p->nwh = waves(K, bh), p->nwp = waves(nt, bp);
+    return true;
+}
+
 int launch_small(const float *S, int B, int K, int T, int w, int along_t, float *out, hipStream_t st) {
     const size_t total = (size_t)B * K * T;
     const int bs = 256;
@@ -137,6 +166,18 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
     Plan p;
     int rc = make_plan(K, T, lh, lp, &p);
     if (rc) return rc;
+    // windows up to 21: the block-split kernel (smh_median_split.h) when its wave budget covers the tile
+    static const bool no_split = getenv("SMH_MEDIAN_NOSPLIT") != nullptr;  // A/B switch for tools/tune_median.py
+    if (const SplitEntry *se = no_split ? nullptr : find_split_kernel(lh, lp)) {
+        Plan q = p;
+        if (make_split_roles(K, p.TT, lh, lp, se->threads / 64, &q)) {
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)se->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
+            dim3 grid(q.ntiles, B), block((q.nwh + q.nwp) * 64);
+            hipLaunchKernelGGL(se->fn, grid, block, q.lds, st, S, harm, perc, K, T, q.TT, q.stride, q.nsh, q.nsp, q.nwh,
+                               harm_tmajor, -__builtin_inff(), __builtin_inff());
+            return smh::launch_status("hpss_median_split_kernel");
+        }
+    }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     dim3 grid(p.ntiles, B), block((p.nwh + p.nwp) * 64);
     hipLaunchKernelGGL(fn, grid, block, p.lds, st, S, harm, perc, K, T, p.TT, p.stride, p.nsh, p.nsp, p.nwh,

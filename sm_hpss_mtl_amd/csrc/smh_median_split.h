@@ -1,0 +1,290 @@
+// Block-split sliding median: the HPSS median kernel for windows up to 21.
+//
+// Same contract and same LDS tile as smh_median_kernel.h (harmonic lanes walk frames, percussive lanes walk bins,
+// 'reflect' boundary, bit-exact selection), but the per-lane window is no longer one sorted array that loses its
+// oldest element at every step (delete = compare + select per slot).  The padded line is cut into blocks of W
+// elements; the window ending at offset p of block k is
+//        (suffix of block k-1 of size a = W-1-p)  U  (prefix of block k of size b = p+1)
+// and both sorted runs only ever GROW, by insertion = one v_med3_f32 per kept slot:
+//   * suffix runs: block k-1 walked backwards once, every size kept in registers (the "history");
+//   * prefix runs: block k walked forwards, in place.
+// The median is the H-th smallest of the union of two sorted runs,
+//        r = min_i max(A[i-1], B[H-i]),   i in [max(0, H+1-b), min(a, H+1)],
+// so of a run of size s only the indices [max(0, s-H-1), min(s-1, H)] are ever read -- by the selection and by the
+// insertion that builds the next size -- and only those are computed and stored.  For W = 17 this is 9.6 med3 +
+// 5.3 max + 2.7 min3 per output instead of the 51 VALU of the delete/insert window (tools/median_split_sim.py
+// checks the scheme and these index ranges against scipy.ndimage.median_filter).
+//
+// Compiled with -fno-honor-nans (build.py): spectrogram magnitudes are finite, and without the flag every
+// fminf/fmaxf on a value loaded from LDS costs an extra canonicalising v_max_f32.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "smh_median_kernel.h"
+
+namespace smh_median {
+
+template <int W>
+struct SplitTraits {
+    static constexpr int H = W / 2;
+    static constexpr int lo(int s) { return s - H - 1 > 0 ? s - H - 1 : 0; }
+    static constexpr int hi(int s) { return s - 1 < H ? s - 1 : H; }
+    static constexpr int off(int s) {  // first register of the run of size s inside the history
+        int o = 0;
+        for (int r = 1; r < s; ++r) o += hi(r) - lo(r) + 1;
+        return o;
+    }
+    static constexpr int HIST = off(W);  // runs of size 1 .. W-1
+};
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (ascending) -- keeps every register-array
+// index a constant expression
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for_down(F &&f) {  // I = E-1 .. B
+    if constexpr (B < E) {
+        f(std::integral_constant<int, E - 1>{});
+        static_for_down<B, E - 1>(f);
+    }
+}
+
+// one slot of "insert x into a sorted run": below/above are the old neighbours (absent at the ends)
+template <bool HasBelow, bool HasAbove>
+__device__ __forceinline__ float insert_slot(float below, float x, float above) {
+    if constexpr (HasBelow && HasAbove) return med3(below, x, above);
+    else if constexpr (HasBelow) return fmaxf(below, x);
+    else if constexpr (HasAbove) return fminf(x, above);
+    else return x;
+}
+
+// History of block e[0..W-1]: suffix runs of size 1..W-1 (run s = sorted e[W-s .. W-1], kept indices only).
+template <int W>
+__device__ __forceinline__ void build_history(const float (&e)[W], float (&h)[SplitTraits<W>::HIST]) {
+    using Tr = SplitTraits<W>;
+    static_for<1, W>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const float x = e[W - s];
+        static_for<Tr::lo(s), Tr::hi(s) + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool has_below = i - 1 >= 0;
+            constexpr bool has_above = i <= s - 2;
+            constexpr int po = Tr::off(s > 1 ? s - 1 : 1), pl = Tr::lo(s > 1 ? s - 1 : 1);
+            const float below = has_below ? h[has_below ? po + (i - 1) - pl : 0] : 0.f;
+            const float above = has_above ? h[has_above ? po + i - pl : 0] : 0.f;
+            h[Tr::off(s) + i - Tr::lo(s)] = insert_slot<has_below, has_above>(below, x, above);
+        });
+    });
+}
+
+// Walk one line that lives in LDS: element(pos) = line[pos * es], outputs p0 .. p0+n_out-1 of an axis of extent n
+// (W/2 + 4 < n).  `n_steps` >= n_out is wave-uniform: every lane of the wave runs the same blocks and lanes with
+// fewer outputs only skip their stores.  Output j goes to obase + boff + j * ostep.
+template <int W, int ES, int STORE>
+__device__ __forceinline__ void split_median_walk(const float *line, int es_rt, int p0, int n_out, int n_steps, int n,
+                                                  char *obase, unsigned boff, unsigned ostep) {
+    using Tr = SplitTraits<W>;
+    constexpr int H = W / 2;
+    const int es = ES > 0 ? ES : es_rt;
+    float e[W];
+    float h[Tr::HIST];
+    float pre[H + 1];
+
+    // block of padded elements q0 .. q0+W-1  (padded index q <-> axis position p0 - H + q).  Positions past the
+    // last one the lane's own outputs need (plast) only feed outputs that are never stored: they are clamped so
+    // that no lane reads outside the part of the tile that was staged for it.
+    const int plast = p0 + n_out - 1 + H;
+    auto load_block = [&](int q0) {
+        const int lo = p0 - H + q0;
+        const bool interior = (lo >= 0) & (lo + W <= n) & (lo + W - 1 <= plast);
+        if (__all(interior)) {
+            const float *src = line + lo * es;
+            static_for<0, W>([&](auto uc) { e[decltype(uc)::value] = src[decltype(uc)::value * es]; });
+        } else {
+            static_for<0, W>([&](auto uc) {
+                const int pos = min(lo + decltype(uc)::value, plast);
+                e[decltype(uc)::value] = line[reflect_hi(reflect_lo(pos), n) * es];
+            });
+        }
+    };
+    // Stores: the byte offset advances by ostep per output (no multiply); the per-lane bound check is only
+    // evaluated in blocks where some lane of the wave may run past its own n_out (`guard`, wave-uniform).
+    unsigned off = boff;
+    auto emit = [&](int j, float v, bool guard) {
+        if (!guard || j < n_out) {
+            float *dst = reinterpret_cast<float *>(obase + off);
+            if constexpr (STORE == kStridedStream) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+        }
+        off += ostep;
+    };
+    const bool ragged = !__all(n_out == n_steps);
+    // block 0: only its last window is an output (the whole block); its history serves block 1
+    load_block(0);
+    build_history<W>(e, h);
+    {
+        constexpr int po = Tr::off(W - 1), pl = Tr::lo(W - 1);
+        emit(0, med3(h[po + (H - 1) - pl], e[0], h[po + H - pl]), ragged);
+    }
+    for (int j0 = 1; j0 < n_steps; j0 += W) {
+        load_block(j0 + W - 1);  // windows ending in this block: outputs j0 .. j0+W-1
+        const int steps = n_steps - j0;  // wave-uniform
+        bool live = true;
+        static_for<0, W>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int b = p + 1, a = W - 1 - p;
+            if (p > 0 && p >= steps) live = false;
+            if (live) {
+                // grow the prefix run to size b (in place, top slot first: old neighbours are still intact)
+                static_for_down<Tr::lo(b), Tr::hi(b) + 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr bool has_below = i - 1 >= 0;
+                    constexpr bool has_above = i <= b - 2;
+                    const float below = has_below ? pre[has_below ? i - 1 : 0] : 0.f;
+                    const float above = has_above ? pre[i] : 0.f;
+                    pre[i] = insert_slot<has_below, has_above>(below, e[p], above);
+                });
+                // H-th smallest of suffix run (size a) U prefix run (size b)
+                constexpr int i_lo = (H + 1 - b) > 0 ? (H + 1 - b) : 0;
+                constexpr int i_hi = a < H + 1 ? a : H + 1;
+                constexpr int ao = Tr::off(a > 0 ? a : 1), al = Tr::lo(a > 0 ? a : 1);
+                float r = 0.f;
+                static_for<i_lo, i_hi + 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    float t;
+                    if constexpr (i == 0) t = pre[H];
+                    else if constexpr (H - i < 0) t = h[ao + (i - 1) - al];
+                    else t = fmaxf(h[ao + (i - 1) - al], pre[H - i]);
+                    r = (i == i_lo) ? t : fminf(r, t);
+                });
+                emit(j0 + p, r, ragged);
+            }
+        });
+        if (j0 + W < n_steps) build_history<W>(e, h);
+    }
+}
+
+// Register budget: the history is H*(H+1)-1 registers (80 for W = 17, 120 for W = 21), so the workgroup size is
+// chosen for 4 waves per SIMD (128 VGPRs) up to W = 17 and 3 waves per SIMD (168 VGPRs) above; two workgroups share
+// a CU (LDS: 2 x 80 KB), one staging its tile while the other computes.
+template <int LH, int LP>
+struct SplitCfg {
+    static constexpr int kMaxW = LH > LP ? LH : LP;
+    static constexpr int kThreads = kMaxW <= 17 ? 512 : 384;
+    static constexpr int kWavesPerSimd = kMaxW <= 17 ? 4 : 3;
+};
+
+// Same arguments and tile as hpss_median_kernel; LH / LP = 0 disables that role.
+template <int LH, int LP>
+__global__ void __launch_bounds__((SplitCfg<LH, LP>::kThreads), (SplitCfg<LH, LP>::kWavesPerSimd))
+hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, float *__restrict__ perc, int K, int T,
+                         int TT, int stride, int nsh, int nsp, int nwh, int harm_tmajor, float, float) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    constexpr int HH = LH / 2;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int t1 = min(T, t0 + TT);
+    const int c0 = max(0, t0 - HH), c1 = min(T, t1 + HH);
+    const int ncols = c1 - c0;
+    const float *Sb = S + (size_t)b * K * T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nwaves = blockDim.x >> 6;
+
+    // stage the tile: one wave per row, kRowBatch rows of loads in flight per wave before the first LDS write
+    constexpr int kRowBatch = 6;
+    if (((T | c0 | ncols) & 1) == 0 && ncols <= 128) {
+        const int n2 = ncols >> 1;
+        for (int k0 = wave; k0 < K; k0 += nwaves * kRowBatch) {
+            float2v v[kRowBatch];
+#pragma unroll
+            for (int r = 0; r < kRowBatch; ++r) {
+                const int k = min(k0 + r * nwaves, K - 1);
+                v[r] = __builtin_nontemporal_load(reinterpret_cast<const float2v *>(Sb + (size_t)k * T + c0) +
+                                                  min(lane, n2 - 1));
+            }
+#pragma unroll
+            for (int r = 0; r < kRowBatch; ++r) {
+                const int k = k0 + r * nwaves;
+                if (k < K && lane < n2) {
+                    tile[k * stride + 2 * lane] = v[r].x;
+                    tile[k * stride + 2 * lane + 1] = v[r].y;
+                }
+            }
+        }
+    } else {
+        for (int k0 = wave; k0 < K; k0 += nwaves * kRowBatch) {
+            for (int cb = 0; cb < ncols; cb += 64) {
+                float v[kRowBatch];
+                const int c = cb + lane;
+#pragma unroll
+                for (int r = 0; r < kRowBatch; ++r) {
+                    const int k = min(k0 + r * nwaves, K - 1);
+                    v[r] = __builtin_nontemporal_load(Sb + (size_t)k * T + c0 + min(c, ncols - 1));
+                }
+#pragma unroll
+                for (int r = 0; r < kRowBatch; ++r) {
+                    const int k = k0 + r * nwaves;
+                    if (k < K && c < ncols) tile[k * stride + c] = v[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nt = t1 - t0;
+    if (wave < nwh) {
+        if constexpr (LH > 0) {
+            // harmonic: task = (segment, bin); the window runs over frames of the WHOLE clip
+            const int id = wave * 64 + lane;
+            if (id < K * nsh) {
+                const int sg = id / K, k = id - sg * K;
+                const int seglen = (nt + nsh - 1) / nsh;
+                const int ts = t0 + sg * seglen;
+                const int te = min(t1, ts + seglen);
+                if (ts < te) {
+                    const float *row = tile + k * stride - c0;
+                    char *ob = reinterpret_cast<char *>(harm + (size_t)b * K * T);
+                    if (harm_tmajor)
+                        split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
+                                                                (unsigned)(ts * K + k) * 4u, (unsigned)K * 4u);
+                    else
+                        split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
+                                                                (unsigned)(k * T + ts) * 4u, 4u);
+                }
+            }
+        }
+    } else {
+        if constexpr (LP > 0) {
+            // percussive: task = (segment, frame); the window runs over bins
+            const int id = (wave - nwh) * 64 + lane;
+            if (id < nt * nsp) {
+                const int sg = id / nt, tt = id - sg * nt;
+                const int seglen = (K + nsp - 1) / nsp;
+                const int ks = sg * seglen;
+                const int ke = min(K, ks + seglen);
+                if (ks < ke) {
+                    const float *col = tile + (t0 + tt - c0);
+                    split_median_walk<LP, 0, kStridedStream>(col, stride, ks, ke - ks, seglen, K,
+                                                             reinterpret_cast<char *>(perc + (size_t)b * K * T),
+                                                             (unsigned)(ks * T + t0 + tt) * 4u, (unsigned)T * 4u);
+                }
+            }
+        }
+    }
+}
+
+constexpr int kSplitMaxWindow = 21;  // 120 history registers; larger windows keep the delete/insert kernel
+
+struct SplitEntry {
+    int lh, lp, threads;
+    KernelFn fn;
+};
+const SplitEntry *find_split_kernel(int lh, int lp);  // smh_median_split.hip
+
+}  // namespace smh_median
