@@ -167,7 +167,35 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
     int rc = make_plan(K, T, lh, lp, &p);
     if (rc) return rc;
     // windows up to 21: the block-split kernel (smh_median_split.h) when its wave budget covers the tile
-    static const bool no_split = getenv("SMH_MEDIAN_NOSPLIT") != nullptr;  // A/B switch for tools/tune_median.py
+    static const bool no_split = getenv("SMH_MEDIAN_NOSPLIT") != nullptr;  // A/B switches for tools/tune_median.py
+    // Whole clip per tile and at least two clips per CU: windows above 17 (history > 128 VGPRs, so only 6 waves per
+    // workgroup otherwise) take the persistent double-buffered kernel, one 8-wave workgroup per CU with 256 VGPRs;
+    // up to 17 two ordinary 8-wave workgroups per CU measure 3-5 % faster (4 waves per SIMD).  SMH_MEDIAN_PERSIST=0/1
+    // forces either, SMH_MEDIAN_PTHREADS picks the 512 / 768 / 1024-thread build (tools/gpu/tune_split.sh).
+    bool want_persist = (lh > 17 || lp > 17);
+    if (const char *ev = getenv("SMH_MEDIAN_PERSIST")) want_persist = atoi(ev) != 0;
+    int pthreads = 512;
+    if (const char *ev = getenv("SMH_MEDIAN_PTHREADS")) pthreads = atoi(ev);
+    if (const PersistEntry *pe = (no_split || !want_persist || !(lh && lp)) ? nullptr : find_persist_kernel(lh, lp, pthreads)) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            SMH_CHECK_HIP(hipGetDevice(&dev));
+            SMH_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        const int tile_bytes = persist_tile_bytes(K, T);
+        const int g = T & 63;
+        const bool conflict_free = (T & 1) || (g % 4 == 2);  // gcd(T, 64) <= 2
+        Plan q = p;
+        if (p.ntiles == 1 && conflict_free && 2 * tile_bytes <= smh::kLdsBytesPerCU && B >= 2 * n_cu &&
+            make_split_roles(K, T, lh, lp, pe->threads / 64, &q)) {
+            const int lds = 2 * tile_bytes;
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)pe->fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(pe->fn, dim3(n_cu), dim3((q.nwh + q.nwp) * 64), lds, st, S, harm, perc, B, K, T, q.nsh,
+                               q.nsp, q.nwh, harm_tmajor);
+            return smh::launch_status("hpss_median_persist_kernel");
+        }
+    }
     if (const SplitEntry *se = no_split ? nullptr : find_split_kernel(lh, lp)) {
         Plan q = p;
         if (make_split_roles(K, p.TT, lh, lp, se->threads / 64, &q)) {

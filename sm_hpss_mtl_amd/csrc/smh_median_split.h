@@ -18,6 +18,7 @@
 // Compiled with -fno-honor-nans (build.py): spectrogram magnitudes are finite, and without the flag every
 // fminf/fmaxf on a value loaded from LDS costs an extra canonicalising v_max_f32.
 #pragma once
+#include <cstdint>
 #include <type_traits>
 #include <utility>
 
@@ -113,8 +114,9 @@ __device__ __forceinline__ void split_median_walk(const float *line, int es_rt, 
             });
         }
     };
-    // Stores: the byte offset advances by ostep per output (no multiply); the per-lane bound check is only
-    // evaluated in blocks where some lane of the wave may run past its own n_out (`guard`, wave-uniform).
+    // Stores: the byte offset advances by ostep per output (no multiply).  Every block runs all W steps as
+    // straight-line code (elements past a lane's range are clamped duplicates); only the blocks in which some lane
+    // of the wave runs past its own n_out (!FAST) pay for the per-lane bound check on the store.
     unsigned off = boff;
     auto emit = [&](int j, float v, bool guard) {
         if (!guard || j < n_out) {
@@ -124,23 +126,16 @@ __device__ __forceinline__ void split_median_walk(const float *line, int es_rt, 
         }
         off += ostep;
     };
-    const bool ragged = !__all(n_out == n_steps);
-    // block 0: only its last window is an output (the whole block); its history serves block 1
-    load_block(0);
-    build_history<W>(e, h);
-    {
-        constexpr int po = Tr::off(W - 1), pl = Tr::lo(W - 1);
-        emit(0, med3(h[po + (H - 1) - pl], e[0], h[po + H - pl]), ragged);
-    }
-    for (int j0 = 1; j0 < n_steps; j0 += W) {
-        load_block(j0 + W - 1);  // windows ending in this block: outputs j0 .. j0+W-1
-        const int steps = n_steps - j0;  // wave-uniform
-        bool live = true;
+    int n_min = n_out;  // smallest n_out among the lanes of this wave
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n_min = min(n_min, __shfl_xor(n_min, o, 64));
+
+    auto forward = [&](auto fast_c, int j0) {
+        constexpr bool FAST = decltype(fast_c)::value;
         static_for<0, W>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             constexpr int b = p + 1, a = W - 1 - p;
-            if (p > 0 && p >= steps) live = false;
-            if (live) {
+            {
                 // grow the prefix run to size b (in place, top slot first: old neighbours are still intact)
                 static_for_down<Tr::lo(b), Tr::hi(b) + 1>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
@@ -163,9 +158,22 @@ __device__ __forceinline__ void split_median_walk(const float *line, int es_rt, 
                     else t = fmaxf(h[ao + (i - 1) - al], pre[H - i]);
                     r = (i == i_lo) ? t : fminf(r, t);
                 });
-                emit(j0 + p, r, ragged);
+                emit(j0 + p, r, !FAST);
             }
         });
+    };
+
+    // block 0: only its last window is an output (the whole block); its history serves block 1
+    load_block(0);
+    build_history<W>(e, h);
+    {
+        constexpr int po = Tr::off(W - 1), pl = Tr::lo(W - 1);
+        emit(0, med3(h[po + (H - 1) - pl], e[0], h[po + H - pl]), false);  // n_out >= 1
+    }
+    for (int j0 = 1; j0 < n_steps; j0 += W) {
+        load_block(j0 + W - 1);  // windows ending in this block: outputs j0 .. j0+W-1
+        if (j0 + W <= n_min) forward(std::true_type{}, j0);
+        else forward(std::false_type{}, j0);
         if (j0 + W < n_steps) build_history<W>(e, h);
     }
 }
@@ -178,6 +186,8 @@ struct SplitCfg {
     static constexpr int kMaxW = LH > LP ? LH : LP;
     static constexpr int kThreads = kMaxW <= 17 ? 512 : 384;
     static constexpr int kWavesPerSimd = kMaxW <= 17 ? 4 : 3;
+    // float2 loads in flight per lane in the flat tile load: batch x threads x 2 >= 201 x 98 (the reference clip)
+    static constexpr int kFlatBatch = kMaxW <= 17 ? 20 : 27;
 };
 
 // Same arguments and tile as hpss_median_kernel; LH / LP = 0 disables that role.
@@ -196,9 +206,33 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nwaves = blockDim.x >> 6;
 
-    // stage the tile: one wave per row, kRowBatch rows of loads in flight per wave before the first LDS write
-    constexpr int kRowBatch = 6;
-    if (((T | c0 | ncols) & 1) == 0 && ncols <= 128) {
+    // stage the tile.  Whole clip in one tile (the common case): the K x T block is contiguous in HBM, so it is read
+    // as one flat float2 stream with every load of a lane in flight at once (a single HBM round trip per workgroup)
+    // and scattered to the odd-stride tile: element g = k*T + t lands at g + k*(stride - T).
+    constexpr int kFlatBatch = SplitCfg<LH, LP>::kFlatBatch;
+    if (TT >= T && ((K * T) & 1) == 0 && K * T <= kFlatBatch * 2 * (int)blockDim.x) {
+        const int n2 = (K * T) >> 1;
+        const float2v *src = reinterpret_cast<const float2v *>(Sb);
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)T + 1u;  // g / T == umulhi(g, magic) for g * T < 2^32
+        const int extra = stride - T;
+        float2v v[kFlatBatch];
+#pragma unroll
+        for (int r = 0; r < kFlatBatch; ++r) {
+            const int idx = r * (int)blockDim.x + (int)threadIdx.x;
+            v[r] = __builtin_nontemporal_load(src + min(idx, n2 - 1));
+        }
+#pragma unroll
+        for (int r = 0; r < kFlatBatch; ++r) {
+            const int idx = r * (int)blockDim.x + (int)threadIdx.x;
+            if (idx < n2) {
+                const unsigned g = 2u * (unsigned)idx;
+                const unsigned k0 = __umulhi(g, magic), k1 = __umulhi(g + 1u, magic);
+                tile[g + k0 * extra] = v[r].x;
+                tile[g + 1u + k1 * extra] = v[r].y;
+            }
+        }
+    } else if (((T | c0 | ncols) & 1) == 0 && ncols <= 128) {
+        constexpr int kRowBatch = 6;
         const int n2 = ncols >> 1;
         for (int k0 = wave; k0 < K; k0 += nwaves * kRowBatch) {
             float2v v[kRowBatch];
@@ -218,6 +252,7 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
             }
         }
     } else {
+        constexpr int kRowBatch = 6;
         for (int k0 = wave; k0 < K; k0 += nwaves * kRowBatch) {
             for (int cb = 0; cb < ncols; cb += 64) {
                 float v[kRowBatch];
@@ -278,6 +313,93 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
         }
     }
 }
+
+// ---- persistent form for whole-clip tiles (the fused pipeline at batch >= 2 x CUs) --------------------------------
+// One workgroup per CU loops over clips b = blockIdx.x, + gridDim.x, ... with TWO tiles in LDS: while the 8 waves
+// compute on one, the next clip streams into the other by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write).
+// The DMA writes LDS linearly, so the tile is the flat K x T image (row stride T): conflict-free for the harmonic
+// lanes (lane <-> bin) whenever gcd(T, 64) <= 2 -- T = 98 -- because ds_read_b32 is serviced in 32-lane halves.
+// A clip need not start on a 16-byte boundary (K*T*4 = 78 792 B): the copy starts at the aligned address below it
+// and the tile pointer is moved up by the same `mis` bytes.
+__host__ __device__ constexpr int persist_tile_bytes(int K, int T) { return ((K * T * 4 + 16) + 1023) & ~1023; }
+
+// THREADS = 512 / 768 / 1024: 2 / 3 / 4 waves per SIMD and 256 / 168 / 128 VGPRs per lane.
+template <int LH, int LP, int THREADS>
+__global__ void __launch_bounds__(THREADS, (THREADS / 256))
+hpss_median_persist_kernel(const float *__restrict__ S, float *__restrict__ harm, float *__restrict__ perc, int B, int K,
+                           int T, int nsh, int nsp, int nwh, int harm_tmajor) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tile_bytes = persist_tile_bytes(K, T);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nwaves = blockDim.x >> 6;
+    const size_t clip_bytes = (size_t)K * T * 4;
+
+    auto issue_load = [&](int b, int buf) {
+        const char *src = reinterpret_cast<const char *>(S) + (size_t)b * clip_bytes;
+        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+        src -= mis;
+        const int nchunks = ((int)clip_bytes + mis + 15) >> 4;
+        char *dst = lds + buf * tile_bytes;
+        for (int i = wave; i * 64 < nchunks; i += nwaves) {
+            const int c = i * 64 + lane;
+            if (c < nchunks)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + (size_t)c * 16),
+                    (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int b = blockIdx.x;
+    if (b >= B) return;
+    issue_load(b, 0);
+    for (int it = 0; b < B; b += gridDim.x, ++it) {
+        const int cur = it & 1;
+        // tile `cur` has landed (each wave drains its own DMAs) and every wave is done with tile cur^1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (b + (int)gridDim.x < B) issue_load(b + gridDim.x, cur ^ 1);
+        const int mis = (int)((reinterpret_cast<uintptr_t>(S) + (size_t)b * clip_bytes) & 15);
+        const float *tile = reinterpret_cast<const float *>(lds + cur * tile_bytes + mis);
+        if (wave < nwh) {
+            const int id = wave * 64 + lane;
+            if (id < K * nsh) {
+                const int sg = id / K, k = id - sg * K;
+                const int seglen = (T + nsh - 1) / nsh;
+                const int ts = sg * seglen;
+                const int te = min(T, ts + seglen);
+                if (ts < te) {
+                    const float *row = tile + k * T;
+                    char *ob = reinterpret_cast<char *>(harm + (size_t)b * K * T);
+                    if (harm_tmajor)
+                        split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
+                                                                (unsigned)(ts * K + k) * 4u, (unsigned)K * 4u);
+                    else
+                        split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
+                                                                (unsigned)(k * T + ts) * 4u, 4u);
+                }
+            }
+        } else {
+            const int id = (wave - nwh) * 64 + lane;
+            if (id < T * nsp) {
+                const int sg = id / T, tt = id - sg * T;
+                const int seglen = (K + nsp - 1) / nsp;
+                const int ks = sg * seglen;
+                const int ke = min(K, ks + seglen);
+                if (ks < ke)
+                    split_median_walk<LP, 0, kStridedStream>(tile + tt, T, ks, ke - ks, seglen, K,
+                                                             reinterpret_cast<char *>(perc + (size_t)b * K * T),
+                                                             (unsigned)(ks * T + tt) * 4u, (unsigned)T * 4u);
+            }
+        }
+    }
+}
+
+using PersistFn = void (*)(const float *, float *, float *, int, int, int, int, int, int, int);
+struct PersistEntry {
+    int lh, lp, threads;
+    PersistFn fn;
+};
+const PersistEntry *find_persist_kernel(int lh, int lp, int threads);  // smh_median_split.hip
 
 constexpr int kSplitMaxWindow = 21;  // 120 history registers; larger windows keep the delete/insert kernel
 

@@ -19,4 +19,15 @@ const SplitEntry *find_split_kernel(int lh, int lp) {
     return nullptr;
 }
 
+#define SMH_PERSIST_E3(a, b, t) {a, b, t, hpss_median_persist_kernel<a, b, t>},
+#define SMH_PERSIST_E2(a, b) SMH_PERSIST_E3(a, b, 512) SMH_PERSIST_E3(a, b, 768)
+const PersistEntry kPersist[] = {SMH_PERSIST_E2(21, 11) SMH_PERSIST_E2(17, 17) SMH_PERSIST_E2(11, 11)
+                                 SMH_PERSIST_E2(11, 21) SMH_PERSIST_E2(21, 21) SMH_PERSIST_E3(17, 17, 1024)};
+
+const PersistEntry *find_persist_kernel(int lh, int lp, int threads) {
+    for (const PersistEntry &e : kPersist)
+        if (e.lh == lh && e.lp == lp && e.threads == threads) return &e;
+    return nullptr;
+}
+
 }  // namespace smh_median

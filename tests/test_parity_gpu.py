@@ -64,6 +64,38 @@ def test_hpss_median_bit_exact(fe, clips4, lh, lp):
         assert np.array_equal(perc[i], ofe.median_freq(S[i], lp)), "perc differs"
 
 
+@pytest.mark.parametrize("lh,lp,B,persist", [(17, 17, 1024, None), (21, 11, 1024, None), (17, 17, 515, "1"),
+                                              (11, 21, 700, None), (21, 21, 513, None), (21, 11, 1024, "0")])
+def test_hpss_median_large_batch_bit_exact(fe, lh, lp, B, persist, monkeypatch):
+    """Batches of at least two clips per CU: windows above 17 take the persistent double-buffered kernel (LDS-DMA
+    tile loads, clips that start on 8-byte boundaries, uneven clips per workgroup), the others the ordinary
+    block-split kernel; SMH_MEDIAN_PERSIST forces either.  Every clip must be bit-exact."""
+    if persist is not None:
+        monkeypatch.setenv("SMH_MEDIAN_PERSIST", persist)
+    from sm_hpss_mtl_amd.synth import synth_clips
+    base = synth_clips(24, seed=77)
+    Sb = np.stack([ofe.stft_mag(c) for c in base])
+    idx = (np.arange(B) * 7) % 24  # clip b is base clip idx[b]
+    S = dev(Sb[idx])
+    harm, perc = fe.hpss_median(S, lh, lp)
+    ref_h = dev(np.stack([ofe.median_time(x, lh) for x in Sb]))
+    ref_p = dev(np.stack([ofe.median_freq(x, lp) for x in Sb]))
+    sel = torch.from_numpy(idx).cuda()
+    torch.cuda.synchronize()
+    assert torch.equal(harm, ref_h[sel]), "harm differs"
+    assert torch.equal(perc, ref_p[sel]), "perc differs"
+    # time-major harmonic output of the fused pipeline
+    h2, p2 = torch.empty_like(S), torch.empty_like(S)
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    lay = _lib.check(fe.lib.smh_hpss_median_ex_f32(fe._h, ptr(S), B, 201, 98, lh, lp, ptr(h2), ptr(p2), 1,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert lay == 1
+    assert torch.equal(h2.view(B, 98, 201), ref_h[sel].transpose(1, 2)) and torch.equal(p2, ref_p[sel])
+
+
 def test_median_golden_scipy(fe, golden_fe):
     S = golden_fe["S"][None]
     harm, perc = fe.hpss_median(dev(S), 21, 11)

@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -m gpu -q --timeout 300 -p no:cacheprovider -x -k "median or hpss or frontend or fused or pipeline or feature" > gpurun_out/pytest_median.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -m gpu -q --timeout 300 -p no:cacheprovider -x -k "median or hpss or frontend or fused or pipeline or feature or full or batch" > gpurun_out/pytest_median.log 2>&1; rc=$?
 echo "pytest rc=$rc"; tail -15 gpurun_out/pytest_median.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_split.log 2>&1; rc=$?
