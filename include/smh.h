@@ -188,6 +188,38 @@ int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_
 /* download the (device-resident, possibly trained) weights in canonical order */
 int smh_model_get_weights(const smh_model *m, float *h_flat, size_t n, void *stream);
 
+/* ---- a13: Conv2D MTL baselines, inference forward (lib/proposed_architectures.py:425-511 Doukhan, :516-588
+ * Papakostas, :650-764 Jang; heads :25-80).  Input: (N, in_h, in_w) float32 images = the (nP, 2F, W, 1) patches of
+ * get_feature_patches for the non-Lemaire models (lib/preprocessing.py:216-217,226-227).  Output row =
+ * [S | M | (N) | R | 3C], like smh_model_forward_f32.  Weights: one flat float32 vector, tensors in the order
+ * reported by smh_cnn_tensor_info (Keras layouts: Conv2D (kh,kw,Cin,Cout), Dense (in,out), BN gamma/beta/mean/var). */
+enum { SMH_CNN_DOUKHAN = 0, SMH_CNN_PAPAKOSTAS = 1, SMH_CNN_JANG = 2 };
+typedef struct smh_cnn_cfg {
+    int32_t kind;      /* SMH_CNN_* */
+    int32_t in_h;      /* 2*n_mels (Doukhan), 2*(n_fft/2+1) (Papakostas, Jang) */
+    int32_t in_w;      /* patch width W */
+    int32_t n_classes; /* 3 or 5 */
+    int32_t n_mels;    /* Jang: mel-scale kernels per half (0 = 120) */
+    int32_t n_fft;     /* Jang: 0 = 512 */
+    int32_t fc_width;  /* Papakostas: width of the two Dense layers (0 = 4096) */
+    float fs;          /* Jang: sampling rate of the mel filter bank (0 = 16000) */
+} smh_cnn_cfg;
+typedef struct smh_cnn smh_cnn;
+int smh_cnn_create(const smh_cnn_cfg *cfg, smh_cnn **out);
+void smh_cnn_destroy(smh_cnn *m);
+size_t smh_cnn_num_params(const smh_cnn *m);
+int smh_cnn_out_dim(const smh_cnn *m);
+int smh_cnn_feat_dim(const smh_cnn *m); /* width of the feature vector the heads read */
+int smh_cnn_num_tensors(const smh_cnn *m);
+/* name (<= name_cap-1 chars), shape (4 ints, unused dims 1), rank and offset (in floats) of parameter tensor i */
+int smh_cnn_tensor_info(const smh_cnn *m, int i, char *name, int name_cap, int *shape4, int *ndim, size_t *offset);
+int smh_cnn_set_weights(smh_cnn *m, const float *h_flat, size_t n, void *stream);
+int smh_cnn_get_weights(const smh_cnn *m, float *h_flat, size_t n, void *stream);
+size_t smh_cnn_workspace_bytes(const smh_cnn *m, int N);
+/* d_x (N, in_h, in_w) -> d_out (N, out_dim); d_feat (N, feat_dim) optional (null to skip) */
+int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
+                        size_t work_bytes, void *stream);
+
 /* ---- a14: one training step = what model.fit runs per batch (Proposed_Work_Results.py:298-307) for the
  * model compiled at lib/proposed_architectures.py:156-165: BCE (S, M[, N]) + MSE (R) + CCE (3C) with optional
  * loss_weights, l2(0.01) on the Dense(16) kernels, SGD(momentum, clipnorm, lr from ExponentialDecay).

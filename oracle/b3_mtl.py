@@ -123,12 +123,24 @@ def _dense(x, k, b):
     return (x.astype(np.float64) @ k.astype(np.float64) + b.astype(np.float64)).astype(np.float32)
 
 
-def forward(x, w, n_classes: int = 3, return_trunk: bool = False):
-    """Inference forward.  x: (N, T, F) float32.  Returns list in Keras output order
-    [S, M, (N,) R, 3C] (proposed_architectures.py:154)."""
-    x = np.asarray(x, dtype=np.float32)
-    trunk = tcn_forward(x, w)
-    flat = trunk.reshape(trunk.shape[0], -1)  # Flatten: (T, C) row-major
+def init_head_weights(w, rng, D: int, n_classes: int = 3):
+    """Append the '3C' classifier and the MTL heads of `MTL_modifications` on a D-wide feature vector."""
+    w["3C/kernel"] = _glorot(rng, (D, n_classes), D, n_classes)
+    w["3C/bias"] = np.zeros(n_classes, np.float32)
+    for name, odim, _ in head_spec(n_classes):
+        w[f"{name}/dense/kernel"] = _glorot(rng, (D, 16), D, 16)
+        w[f"{name}/dense/bias"] = np.zeros(16, np.float32)
+        w[f"{name}/bn/gamma"] = np.ones(16, np.float32)
+        w[f"{name}/bn/beta"] = np.zeros(16, np.float32)
+        w[f"{name}/bn/moving_mean"] = np.zeros(16, np.float32)
+        w[f"{name}/bn/moving_variance"] = np.ones(16, np.float32)
+        w[f"{name}/out/kernel"] = _glorot(rng, (16, odim), 16, odim)
+        w[f"{name}/out/bias"] = np.zeros(odim, np.float32)
+
+
+def mtl_heads(flat, w, n_classes: int = 3):
+    """lib/proposed_architectures.py:25-80 + the '3C' softmax on the same features: list in Keras output order
+    [S, M, (N,) R, 3C]."""
     outs = []
     for name, _, act in head_spec(n_classes):
         h = _dense(flat, w[f"{name}/dense/kernel"], w[f"{name}/dense/bias"])
@@ -143,6 +155,16 @@ def forward(x, w, n_classes: int = 3, return_trunk: bool = False):
     logits -= logits.max(axis=1, keepdims=True)
     e = np.exp(logits)
     outs.append((e / e.sum(axis=1, keepdims=True)).astype(np.float32))
+    return outs
+
+
+def forward(x, w, n_classes: int = 3, return_trunk: bool = False):
+    """Inference forward.  x: (N, T, F) float32.  Returns list in Keras output order
+    [S, M, (N,) R, 3C] (proposed_architectures.py:154)."""
+    x = np.asarray(x, dtype=np.float32)
+    trunk = tcn_forward(x, w)
+    flat = trunk.reshape(trunk.shape[0], -1)  # Flatten: (T, C) row-major
+    outs = mtl_heads(flat, w, n_classes)
     if return_trunk:
         return outs, trunk
     return outs

@@ -22,6 +22,11 @@ class ModelCfg(C.Structure):
                 ("n_dilations", C.c_int32)]
 
 
+class CnnCfg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("n_classes", C.c_int32),
+                ("n_mels", C.c_int32), ("n_fft", C.c_int32), ("fc_width", C.c_int32), ("fs", C.c_float)]
+
+
 _vp, _i, _sz, _fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p  # device pointers travel as void*
 
 # name -> (restype, argtypes): exactly the declarations of include/smh.h
@@ -65,6 +70,17 @@ SIGNATURES = {
     "smh_model_out_dim": (_i, [_vp]),
     "smh_model_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "smh_model_get_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "smh_cnn_create": (_i, [C.POINTER(CnnCfg), C.POINTER(_vp)]),
+    "smh_cnn_destroy": (None, [_vp]),
+    "smh_cnn_num_params": (_sz, [_vp]),
+    "smh_cnn_out_dim": (_i, [_vp]),
+    "smh_cnn_feat_dim": (_i, [_vp]),
+    "smh_cnn_num_tensors": (_i, [_vp]),
+    "smh_cnn_tensor_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "smh_cnn_set_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "smh_cnn_get_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "smh_cnn_workspace_bytes": (_sz, [_vp, _i]),
+    "smh_cnn_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_trainer_create": (_i, [_vp, _i, C.POINTER(_vp)]),
     "smh_trainer_destroy": (None, [_vp]),
     "smh_trainer_grad_ptr": (_vp, [_vp]),
