@@ -161,6 +161,14 @@ int smh_remove_silence_f32(const float *d_x, int B, int N, const float *d_energy
 int smh_preprocess_signal_f32(const float *d_x, int B, int N, int fs, int Tw, int Ts, float *d_out, int *d_n_keep,
                               void *d_work, size_t work_bytes, void *stream);
 
+/* ---- 8f rank 2: mix_signals(Xin_sp, Xin_mu, target_dB) (lib/preprocessing.py:297-325) for B pairs of clips ------
+ * d_sp (B, N) speech, d_mu (B, N_mu) music (looped to N when shorter, cut when longer), d_target_db (B) SMR in dB ->
+ * d_out (B, N): music scaled to the target speech-to-music ratio, both weighted so the factors sum to one, then the
+ * reference's normalisation.  Energies are f64 ordered sums (numpy: pairwise f32).  Workspace:
+ * smh_normalize_workspace_bytes(B, N).                                                                          */
+int smh_mix_signals_f32(const float *d_sp, const float *d_mu, int B, int N, int N_mu, const float *d_target_db,
+                        float *d_out, void *d_work, size_t work_bytes, void *stream);
+
 /* ---- a10-a12: B3_MTL = get_Lemaire_MTL_model (lib/proposed_architectures.py:85-170, 25-80) ---- */
 typedef struct smh_model_cfg {
     int32_t n_feat;     /* N_MELS argument = input_shape[1]: 240                       */

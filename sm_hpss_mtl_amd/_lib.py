@@ -63,6 +63,7 @@ SIGNATURES = {
     "smh_remove_silence_f32": (_i, [_fp, _i, _i, _fp, _i, _i, _i, _i, C.c_double, C.c_double, _fp, _vp, _vp, _vp, _vp,
                                     _sz, _vp]),
     "smh_preprocess_signal_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _sz, _vp]),
+    "smh_mix_signals_f32": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "smh_model_destroy": (None, [_vp]),
     "smh_model_num_params": (_sz, [_vp]),

@@ -47,7 +47,7 @@ SilWork carve(void *base, int B, int N, int hop, bool with_signal = true) {
         return (void *)q;
     };
     const size_t b = (size_t)(B > 0 ? B : 1);
-    w.psum = (double *)take(b * w.nchunk * sizeof(double));
+    w.psum = (double *)take(2 * b * w.nchunk * sizeof(double));  // two rows per clip for mix_signals
     w.mean = (float *)take(b * sizeof(float));
     w.absmax = (unsigned *)take(b * sizeof(unsigned));
     w.emax = (unsigned *)take(b * sizeof(unsigned));
@@ -487,6 +487,63 @@ __global__ __launch_bounds__(kFusedThreads) void preprocess_fused_kernel(const f
     }
 }
 
+// ---- mix_signals (preprocessing.py:297-325): music looped to the speech length, scaled to the target SMR --------
+// pass 1: ordered f64 partial sums of sp^2 and (looped mu)^2 per chunk
+__global__ __launch_bounds__(kThreads) void mix_energy_kernel(const float *__restrict__ sp, const float *__restrict__ mu,
+                                                              int N, int Nmu, int nchunk, double *__restrict__ psum) {
+    const int b = blockIdx.y, c = blockIdx.x;
+    const float *s = sp + (size_t)b * N, *m = mu + (size_t)b * Nmu;
+    const int lo = c * kChunk, hi = min(N, lo + kChunk);
+    double es = 0.0, em = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const double a = s[i], v = m[i % Nmu];
+        es += a * a;
+        em += v * v;
+    }
+    __shared__ double sh[2][kThreads / 64];
+    es = wave_sum(es), em = wave_sum(em);
+    if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = es, sh[1][threadIdx.x >> 6] = em;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) t += sh[threadIdx.x][w];
+        psum[((size_t)b * 2 + threadIdx.x) * nchunk + c] = t;
+    }
+}
+
+// pass 2: the two mixing factors per clip (float32, like the float32 audio of the reference)
+__global__ __launch_bounds__(64) void mix_factor_kernel(const double *__restrict__ psum, int N, int nchunk,
+                                                        const float *__restrict__ target_db, float *__restrict__ fac) {
+    const int b = blockIdx.x;
+    double es = 0.0, em = 0.0;
+    for (int c = threadIdx.x; c < nchunk; c += 64) {
+        es += psum[((size_t)b * 2) * nchunk + c];
+        em += psum[((size_t)b * 2 + 1) * nchunk + c];
+    }
+    es = wave_sum(es), em = wave_sum(em);
+    if (threadIdx.x == 0) {
+        const double e_sp = es / N, e_mu = em / N;
+        const double req = e_sp / pow(10.0, (double)target_db[b] / 10.0);
+        double f_mu = sqrt(req / e_mu), f_sp = 1.0;
+        const double sum = f_mu + f_sp;
+        f_mu /= sum, f_sp /= sum;
+        fac[2 * b] = (float)f_sp;
+        fac[2 * b + 1] = (float)f_mu;
+    }
+}
+
+// pass 3: mix = f_sp * sp + f_mu * mu  (two roundings, as numpy evaluates it)
+__global__ __launch_bounds__(kThreads) void mix_write_kernel(const float *__restrict__ sp, const float *__restrict__ mu,
+                                                             int N, int Nmu, const float *__restrict__ fac,
+                                                             float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const float *s = sp + (size_t)b * N, *m = mu + (size_t)b * Nmu;
+    float *o = out + (size_t)b * N;
+    const float fs = fac[2 * b], fm = fac[2 * b + 1];
+    const int lo = blockIdx.x * kChunk, hi = min(N, lo + kChunk);
+    for (int i = lo + threadIdx.x; i < hi; i += kThreads) o[i] = __fadd_rn(__fmul_rn(fs, s[i]), __fmul_rn(fm, m[i % Nmu]));
+}
+
 int check_common(const char *fn, const void *d_x, int B, int N) {
     SMH_REQUIRE(B >= 0 && B <= 65535, "%s: B must be in [0, 65535]", fn);
     SMH_REQUIRE(N >= 1, "%s: N must be >= 1", fn);
@@ -621,4 +678,24 @@ extern "C" int smh_preprocess_signal_f32(const float *d_x, int B, int N, int fs,
                                true, st))
         return rc;                                                                          // :339
     return launch_normalize(d_out, B, N, d_out, w, st);                                     // :348-349
+}
+
+extern "C" int smh_mix_signals_f32(const float *d_sp, const float *d_mu, int B, int N, int N_mu, const float *d_target_db,
+                                   float *d_out, void *d_work, size_t work_bytes, void *stream) {
+    if (int rc = check_common("smh_mix_signals_f32", d_sp, B, N)) return rc;
+    SMH_REQUIRE(N_mu >= 1, "smh_mix_signals_f32: empty music signal");
+    if (B == 0) return SMH_OK;
+    SMH_REQUIRE(d_mu && d_target_db && d_out && d_work, "smh_mix_signals_f32: null argument");
+    const SilWork w = carve(d_work, B, N, N, false);
+    if (work_bytes < w.bytes)
+        return smh::set_error(SMH_E_WORKSPACE, "smh_mix_signals_f32: workspace too small (%zu < %zu bytes)", work_bytes,
+                              w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float *fac = reinterpret_cast<float *>(w.runs);  // 2 floats per clip; the run table is unused here
+    const dim3 grid(w.nchunk, B);
+    hipLaunchKernelGGL(mix_energy_kernel, grid, dim3(kThreads), 0, st, d_sp, d_mu, N, N_mu, w.nchunk, w.psum);
+    hipLaunchKernelGGL(mix_factor_kernel, dim3(B), dim3(64), 0, st, w.psum, N, w.nchunk, d_target_db, fac);
+    hipLaunchKernelGGL(mix_write_kernel, grid, dim3(kThreads), 0, st, d_sp, d_mu, N, N_mu, fac, d_out);
+    if (int rc = smh::launch_status("mix kernels")) return rc;
+    return launch_normalize(d_out, B, N, d_out, w, st);  // preprocessing.py:323 normalize_signal(Xin_mix)
 }

@@ -61,6 +61,12 @@ def mix_signals(Xin_sp, Xin_mu, target_dB):
     return normalize_signal(Xin_mix)
 
 
+def mix_signals_batch(Xin_sp, Xin_mu, target_dB):
+    """Device-resident form of `mix_signals` for float32 CUDA tensors (B, N), (B, N_mu) and B target SMRs."""
+    from .. import silence as _sil
+    return _sil.mix_signals(Xin_sp, Xin_mu, target_dB)
+
+
 def _read_audio(fName, sr=16000):
     """Minimal loader for the 'next' row: .npy (float array already at 16 kHz) or PCM/float .wav."""
     if fName.endswith(".npy"):

@@ -4,6 +4,7 @@
   rms                librosa.feature.rms as called at lib/preprocessing.py:338
   remove_silence     lib/cython_impl/tools.pyx:42-134
   preprocess_signal  lib/preprocessing.py:332-349 in one call
+  mix_signals        lib/preprocessing.py:297-325
 
 All functions take float32 CUDA(=HIP) tensors of shape (B, N) -- B equal-length clips -- and return device
 tensors; the arithmetic happens in libsmh.so (smh_silence.hip).  There is no CPU path.
@@ -92,3 +93,24 @@ def preprocess_signal(x, fs, Tw, Ts):
     _lib.check(lib.smh_preprocess_signal_f32(_ptr(x), B, N, int(fs), int(Tw), int(Ts), _ptr(out), _ptr(n_keep),
                                              _ptr(work), work.numel(), _stream()), "smh_preprocess_signal_f32")
     return out, n_keep
+
+
+def mix_signals(sp, mu, target_db):
+    """lib/preprocessing.py:297-325 for B pairs: sp (B, N), mu (B, N_mu) float32 CUDA tensors, target_db scalar or (B,)
+    -> (B, N) normalised mixtures (music looped to the speech length)."""
+    lib = _lib.require_gpu()
+    sp, mu = _batch(sp, "sp"), _batch(mu, "mu")
+    B, N = sp.shape
+    if mu.shape[0] != B:
+        raise ValueError("mu has %d rows for %d speech clips" % (mu.shape[0], B))
+    db = torch.as_tensor(target_db, dtype=torch.float32, device=sp.device).reshape(-1)
+    if db.numel() == 1:
+        db = db.expand(B)
+    if db.numel() != B:
+        raise ValueError("target_db has %d entries for %d clips" % (db.numel(), B))
+    db = db.contiguous()
+    out = torch.empty_like(sp)
+    work = _work(lib.smh_normalize_workspace_bytes(B, N), sp.device)
+    _lib.check(lib.smh_mix_signals_f32(_ptr(sp), _ptr(mu), B, N, mu.shape[1], _ptr(db), _ptr(out), _ptr(work),
+                                       work.numel(), _stream()), "smh_mix_signals_f32")
+    return out

@@ -184,6 +184,23 @@ def test_large_batch_properties(sil):
     assert torch.max(torch.abs(again - d)) <= 1e-6
 
 
+@pytest.mark.parametrize("n,nmu", [(16000, 16000), (16000, 5000), (12000, 30000), (100003, 40001)])
+def test_mix_signals_vs_oracle(sil, n, nmu):
+    """lib/preprocessing.py:297-325: music looped / cut to the speech length, SMR scaling, renormalisation."""
+    from oracle import frontend as ofe
+    rng = np.random.default_rng(n + nmu)
+    sp = (0.3 * rng.standard_normal((3, n))).astype(np.float32)
+    mu = (0.1 * rng.standard_normal((3, nmu)) + 0.02).astype(np.float32)
+    db = np.array([-5.0, 0.0, 20.0], np.float32)
+    out = host(sil.mix_signals(dev(sp), dev(mu), db))
+    for i in range(3):
+        ref = ofe.mix_signals(sp[i], mu[i], float(db[i]))
+        assert out[i].shape == ref.shape and np.max(np.abs(out[i] - ref)) <= 2e-6
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    out2 = host(pp.mix_signals_batch(dev(sp), dev(mu), 10.0))  # one SMR for the whole batch
+    assert np.max(np.abs(out2[1] - ofe.mix_signals(sp[1], mu[1], 10.0))) <= 2e-6
+
+
 def test_error_behaviour(sil):
     x = dev(np.zeros((2, 1000), np.float32))
     with pytest.raises(ValueError):
