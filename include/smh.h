@@ -169,6 +169,11 @@ int smh_preprocess_signal_f32(const float *d_x, int B, int N, int fs, int Tw, in
 int smh_mix_signals_f32(const float *d_sp, const float *d_mu, int B, int N, int N_mu, const float *d_target_db,
                         float *d_out, void *d_work, size_t work_bytes, void *stream);
 
+/* ---- 8f rank 4: scipy.signal.medfilt(x, kernel_size) on B tracks of n values (zero padded, odd window <= 8191),
+ * the smoothing of the frame-level probability track (DAFx12_Speech_Music_Detection_B3_MTL_v2.py:94-98, window 501).
+ * Bit-exact selection.  d_y must not alias d_x.                                                                 */
+int smh_medfilt1d_f32(const float *d_x, int B, int n, int kernel_size, float *d_y, void *stream);
+
 /* ---- a10-a12: B3_MTL = get_Lemaire_MTL_model (lib/proposed_architectures.py:85-170, 25-80) ---- */
 typedef struct smh_model_cfg {
     int32_t n_feat;     /* N_MELS argument = input_shape[1]: 240                       */

@@ -1,0 +1,97 @@
+"""Dense file-level inference and smoothing: device counterpart of
+DAFx12_Speech_Music_Detection_B3_MTL_v2.py:594-706 (`patch_probability_generator`) and :94-98 (`smooth_labels`).
+
+  patch_probabilities   standardise the file's featuregram (:612-626), walk it in 10 000-frame batches (:634-642),
+                        get_feature_patches with shift W_shift_test = 1 (:647), predict one head (:519-523, 661-665)
+  medfilt / smooth_labels   scipy.signal.medfilt(Predictions, 501) and the 0.5 threshold (:96-97)
+
+Everything numeric runs in libsmh.so: StandardScaler rows, the hop-1 patch gather (time-major, straight into the TCN
+layout), the B3_MTL forward, the 501-wide zero-padded median.  No CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .frontend import Frontend, FrontendConfig, _ptr, _stream
+
+_fe = None
+
+
+def _frontend():
+    global _fe
+    if _fe is None:
+        _fe = Frontend(FrontendConfig())
+    return _fe
+
+
+def _dev(x):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return x.float().cuda().contiguous()
+
+
+def medfilt(x, kernel_size):
+    """scipy.signal.medfilt(x, kernel_size) for a 1-D track (or B tracks as rows); numpy in -> numpy out, CUDA
+    tensor in -> CUDA tensor out.  Zero padded, odd window, bit-exact."""
+    lib = _lib.require_gpu()
+    was_np = isinstance(x, np.ndarray)
+    d = _dev(x)
+    one = d.dim() == 1
+    if one:
+        d = d[None]
+    if d.dim() != 2:
+        raise ValueError("medfilt expects a 1-D track or (B, n) tracks, got shape %s" % (tuple(d.shape),))
+    y = torch.empty_like(d)
+    _lib.check(lib.smh_medfilt1d_f32(_ptr(d), d.shape[0], d.shape[1], int(kernel_size), _ptr(y), _stream()),
+               "smh_medfilt1d_f32")
+    y = y[0] if one else y
+    return y.cpu().numpy() if was_np else y
+
+
+def smooth_labels(Predictions, PtdLabels, win_size, smooth_type="prediction"):
+    """DAFx12...:94-98 -> (Predictions_smooth, PtdLabels_smooth)."""
+    if smooth_type != "prediction":
+        raise NotImplementedError("only smooth_type='prediction' (median of the probability track) is built; the "
+                                  "'label' mode filter of :81-89 is plotting support")
+    sm = medfilt(Predictions, win_size)
+    lab = (sm > 0.5).astype(int) if isinstance(sm, np.ndarray) else (sm > 0.5).to(torch.int64)
+    return sm, lab
+
+
+def patch_probabilities(fv, model, W, W_shift=1, output="M", batch_frames=10000):
+    """fv (2R, nFrames) HarmPerc featuregram of one file -> 1-D float32 numpy track of the chosen head's
+    probability, one value per patch, batches concatenated (DAFx12...:612-676)."""
+    fe = _frontend()
+    d = _dev(fv)
+    if d.dim() != 2 or d.shape[0] % 2:
+        raise ValueError("fv must be (2R, nFrames), got %s" % (tuple(d.shape),))
+    names = model.output_names
+    if output not in names:
+        raise ValueError("output %r is not one of %s" % (output, names))
+    col = 0
+    for n, o in zip(names, model.split_outputs(torch.zeros((1, model.out_dim)))):
+        if n == output:
+            break
+        col += o.shape[1]
+    R = d.shape[0] // 2
+    d = torch.cat([fe.standardize_rows(d[:R]), fe.standardize_rows(d[R:])], dim=0)  # :612-626, whole file
+    T = d.shape[1]
+    preds = []
+    for s in range(0, T, batch_frames):
+        e = min(s + batch_frames, T)
+        chunk = d[:, s:e].contiguous()
+        # get_feature_patches on the batch (:647): tile if short, standardise each half over the batch, hop-W_shift
+        # patches; written time-major = the transposed TCN input of :660
+        h = fe.extract_patches(fe.standardize_rows(chunk[:R])[None], W, W_shift, time_major=True)
+        p = fe.extract_patches(fe.standardize_rows(chunk[R:])[None], W, W_shift, time_major=True)
+        if h.shape[0] == 0:
+            continue
+        x = torch.cat([h, p], dim=2)
+        preds.append(model.forward_device(x)[:, col])
+    if not preds:
+        return np.zeros((0,), np.float32)
+    return torch.cat(preds).cpu().numpy()

@@ -1,0 +1,52 @@
+"""GPU parity of the dense file-level inference: the 501-wide zero-padded median (bit-exact) and
+the batched hop-1 patch -> B3_MTL head track against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import b3_mtl
+from oracle import frontend as ofe
+from oracle import inference as oinf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,k", [(3000, 501), (300, 501), (1000, 5), (257, 1), (100000, 501), (50, 99)])
+def test_medfilt_bit_exact(n, k):
+    from sm_hpss_mtl_amd import inference as inf
+    rng = np.random.default_rng(n)
+    x = rng.random(n).astype(np.float32)
+    x[rng.integers(0, n, n // 5)] = x[0]          # ties
+    x[rng.integers(0, n, n // 10)] *= -1.0        # generic medfilt: negative values order correctly too
+    assert np.array_equal(inf.medfilt(x, k), oinf.medfilt(x, k))
+    xb = np.stack([x, x[::-1].copy()])
+    yb = inf.medfilt(torch.from_numpy(xb).cuda(), k)
+    assert isinstance(yb, torch.Tensor) and np.array_equal(yb.cpu().numpy()[1], oinf.medfilt(xb[1], k))
+    with pytest.raises(ValueError):
+        inf.medfilt(x, 500)
+
+
+def test_smooth_labels_signature():
+    from sm_hpss_mtl_amd import inference as inf
+    p = np.random.default_rng(0).random(2000).astype(np.float32)
+    sm, lab = inf.smooth_labels(p, None, 501, smooth_type="prediction")
+    ref_sm, ref_lab = oinf.smooth_labels(p, 501)
+    assert np.array_equal(sm, ref_sm) and np.array_equal(lab, ref_lab)
+
+
+@pytest.mark.parametrize("head", ["M", "S"])
+def test_patch_probabilities_vs_oracle(head):
+    """A 3-second 'file' walked in batches of 120 frames (two full batches, a short one that is tiled)."""
+    from sm_hpss_mtl_amd import inference as inf
+    from sm_hpss_mtl_amd.model import B3MTL
+    from sm_hpss_mtl_amd.synth import synth_clips
+    y = synth_clips(1, seed=3, n_samples=48000)[0]
+    fv = ofe.featuregram(y, "LogMelHarmPercSpec")
+    assert fv.shape == (240, 298)
+    w = b3_mtl.init_weights(seed=2, n_feat=240, patch_size=68, n_classes=3, randomize_bn=True)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=3, seed=0)
+    m.set_weights_dict(w)
+    got = inf.patch_probabilities(fv, m, 68, 1, output=head, batch_frames=120)
+    ref = oinf.patch_probabilities(fv, w, 68, 1, output=head, batch_frames=120)
+    assert got.shape == ref.shape and got.shape[0] == 2 * (120 - 68) + len(ofe.patch_starts(116, 68, 1))
+    assert np.max(np.abs(got - ref)) <= 1e-4

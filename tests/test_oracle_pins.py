@@ -209,3 +209,13 @@ def test_rms_closed_form():
     yp = np.concatenate([y[200:0:-1], y, y[-2:-202:-1]])  # numpy 'reflect': no edge repeat
     for t in (0, 3, len(e) - 1):
         assert abs(e[t] - np.sqrt(np.mean(yp[t * 160:t * 160 + 400].astype(np.float64) ** 2))) < 1e-6
+
+
+@pytest.mark.parametrize("n,k", [(40, 5), (1000, 501), (300, 501), (7, 9), (64, 1)])
+def test_oracle_medfilt_vs_scipy(n, k):
+    """scipy.signal.medfilt is the routine DAFx12...:96 calls."""
+    ss = pytest.importorskip("scipy.signal")
+    from oracle import inference as oinf
+    x = np.random.default_rng(n + k).random(n).astype(np.float32)
+    x[::7] = x[0]
+    assert np.array_equal(oinf.medfilt(x, k), ss.medfilt(x, k))
