@@ -56,5 +56,14 @@ struct smh_ctx {
     float *d_mel_w;    // (nnz)
     int mel_nnz;
     int mel_max_taps;
+    // bin-walk form of the fused feature kernel (smh_feat.hip): the feature rows are cut into segments of similar
+    // bin counts; for every bin of a segment the plan holds how many finished filters to emit first and the weights
+    // of the (at most four) pending ones -- {w0, w1, w2, w3, n_emit, -, -, -} per bin, 32 bytes
+    static constexpr int kMaxFeatSegs = 8;
+    int feat_walk_ok;
+    int feat_nseg;
+    int feat_m0[kMaxFeatSegs], feat_m1[kMaxFeatSegs], feat_kbeg[kMaxFeatSegs], feat_kend[kMaxFeatSegs],
+        feat_off[kMaxFeatSegs];
+    float *d_feat_plan;
     std::vector<float> h_mel_dense;  // (n_mels, K) host copy
 };

@@ -1,4 +1,5 @@
 // Context (constant tables), error reporting and the integer contracts of the hot path.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -184,6 +185,55 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
         if (mw.empty()) mw.push_back(0.f);
     }
     c->mel_nnz = (int)mw.size();
+    std::vector<float> plan;
+    {   // plan of the bin-walk feature kernel
+        const int R = c->feat_rows, NS = smh_ctx::kMaxFeatSegs;
+        std::vector<int> st(R), en(R);
+        for (int i = 0; i < R; ++i) {
+            st[i] = c->n_mels > 0 ? mstart[i] : i;
+            en[i] = st[i] + (c->n_mels > 0 ? mcount[i] : 1);
+        }
+        auto weight = [&](int m, int k) { return c->n_mels > 0 ? mw[moff[m] + (k - st[m])] : 1.0f; };
+        bool ok = true;
+        int bound[NS + 1];
+        bound[0] = 0;
+        for (int sgm = 1; sgm < NS; ++sgm) {  // boundaries where the filter start crosses sgm/NS of the bins
+            int m = bound[sgm - 1];
+            while (m < R && st[m] < (long)c->K * sgm / NS) ++m;
+            bound[sgm] = m;
+        }
+        bound[NS] = R;
+        c->feat_nseg = 0;
+        for (int sgm = 0; sgm < NS; ++sgm) {
+            const int m0 = bound[sgm], m1 = bound[sgm + 1];
+            if (m0 >= m1) continue;
+            int kbeg = c->K, kend = 0;
+            for (int m = m0; m < m1; ++m)
+                if (en[m] > st[m]) kbeg = std::min(kbeg, st[m]), kend = std::max(kend, en[m]);
+            if (kend <= kbeg) kbeg = kend = 0;
+            const int q = c->feat_nseg++;
+            c->feat_m0[q] = m0, c->feat_m1[q] = m1, c->feat_kbeg[q] = kbeg, c->feat_kend[q] = kend;
+            c->feat_off[q] = (int)plan.size();
+            int mcur = m0;
+            for (int k = kbeg; k < kend; ++k) {
+                int nemit = 0;
+                while (mcur < m1 && k >= en[mcur]) ++mcur, ++nemit;
+                float w4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int m = m0; m < m1; ++m)
+                    if (st[m] <= k && k < en[m]) {
+                        if (m < mcur || m > mcur + 3) ok = false;  // more than four pending filters, or out of order
+                        else w4[m - mcur] = weight(m, k);
+                    }
+                for (int e = 0; e < 4; ++e) plan.push_back(w4[e]);
+                float ne;
+                std::memcpy(&ne, &nemit, sizeof(float));
+                plan.push_back(ne);
+                plan.push_back(0.f), plan.push_back(0.f), plan.push_back(0.f);
+            }
+        }
+        c->feat_walk_ok = ok ? 1 : 0;
+        if (plan.empty()) plan.push_back(0.f);
+    }
 
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload(&c->d_window, win);
@@ -193,6 +243,7 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
     if (e == hipSuccess) e = upload(&c->d_mel_count, mcount);
     if (e == hipSuccess) e = upload(&c->d_mel_off, moff);
     if (e == hipSuccess) e = upload(&c->d_mel_w, mw);
+    if (e == hipSuccess) e = upload(&c->d_feat_plan, plan);
     if (e != hipSuccess) {
         smh_ctx_destroy(c);
         return smh::set_error(SMH_E_HIP, "smh_ctx_create: table upload failed: %s", hipGetErrorString(e));
@@ -206,6 +257,7 @@ extern "C" void smh_ctx_destroy(smh_ctx *c) {
     (void)hipFree(c->d_window);
     (void)hipFree(c->d_twM);
     (void)hipFree(c->d_tw2M);
+    (void)hipFree(c->d_feat_plan);
     (void)hipFree(c->d_mel_start);
     (void)hipFree(c->d_mel_count);
     (void)hipFree(c->d_mel_off);

@@ -1,7 +1,9 @@
 // a3-a8: soft masks, mel projection, power_to_db, per-row standardisation, patch extraction.
 // Stand-alone entry points mirror the reference's individual calls (parity API); the two fused kernels
 // at the bottom (hp_feat_kernel, std_patch_kernel) are what smh_frontend_f32 runs.
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "smh_common.h"
 #include "smh_feat.h"
@@ -292,6 +294,129 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// fused fast path, kernel 1 in its bin-walk form (the default): one workgroup per clip, lane <-> frame.  A wave
+// walks the bins of its row segment ONCE: the soft masks of a bin are evaluated once (not once per filter tap) and
+// added into the accumulators of the at most four filters pending at that bin; a filter is emitted (dB, store,
+// running maximum) when the walk has passed its last bin.  Which filters are pending, their weights and the emit
+// points are the same for every lane, so they are precomputed per context as a per-bin plan
+// {w0, w1, w2, w3, n_emit} (smh_ctx.hip) that the wave reads with scalar loads, eight bins ahead together with the
+// vector loads of S and perc -- nothing in the loop depends on a table lookup.  S and perc rows are read coalesced
+// along frames, every element once; the time-major harm clip is copied to LDS (odd row stride) and read column-wise.
+// ---------------------------------------------------------------------------------------------------
+struct FeatPlan {
+    int nseg;
+    int m0[smh_ctx::kMaxFeatSegs], m1[smh_ctx::kMaxFeatSegs], kbeg[smh_ctx::kMaxFeatSegs], kend[smh_ctx::kMaxFeatSegs],
+        off[smh_ctx::kMaxFeatSegs];
+    const float *plan;
+};
+constexpr int kWalkBatch = 8;  // bins of loads in flight per lane
+
+__global__ void __launch_bounds__(1024)
+hp_feat_walk_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const float *__restrict__ harm,
+                    const float *__restrict__ perc, int harm_tmajor, int K, int T, int rows, float *__restrict__ fv,
+                    int *__restrict__ maxkeys) {
+    // LDS: [harm clip T x KP (time-major input only)] [32 ints]: 98 x 201 x 4 + 128 = 78 920 B, two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int b = blockIdx.x;
+    const int KP = K | 1;
+    int *smax = reinterpret_cast<int *>(hs + (harm_tmajor ? (size_t)T * KP : 0));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const size_t cb = (size_t)b * K * T;
+    if (harm_tmajor) {  // straight copy, rows of K floats -> rows of KP
+        constexpr int kB = 4;
+        for (int c0 = wave; c0 < T; c0 += nw * kB) {
+            for (int kb = 0; kb < K; kb += 64) {
+                float v[kB];
+                const int k = kb + lane;
+#pragma unroll
+                for (int r = 0; r < kB; ++r) v[r] = harm[cb + (size_t)min(c0 + r * nw, T - 1) * K + min(k, K - 1)];
+#pragma unroll
+                for (int r = 0; r < kB; ++r) {
+                    const int c = c0 + r * nw;
+                    if (c < T && k < K) hs[c * KP + k] = v[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const int nwt = (T + 63) >> 6;  // waves per segment
+    float mxH = -FLT_MAX, mxP = -FLT_MAX;
+    for (int task = wave; task < fp.nseg * nwt; task += nw) {
+        const int seg = __builtin_amdgcn_readfirstlane(task / nwt);
+        const int tw = task - seg * nwt;
+        const int t = tw * 64 + lane;
+        const bool active = t < T;
+        const int tc = min(t, T - 1);
+        const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
+        int mcur = fp.m0[seg];
+        const float *plan = fp.plan + fp.off[seg];
+        float aH[4] = {0.f, 0.f, 0.f, 0.f}, aP[4] = {0.f, 0.f, 0.f, 0.f};
+        float *fvH = fv + (size_t)b * 2 * rows * T + tc;
+        float *fvP = fvH + (size_t)rows * T;
+        auto emit_first = [&]() {
+            float vH = aH[0], vP = aP[0];
+            if (log_db) {
+                vH = db_of_sq_fast(vH), vP = db_of_sq_fast(vP);
+                mxH = fmaxf(mxH, vH), mxP = fmaxf(mxP, vP);
+            }
+            if (active) {
+                fvH[(size_t)mcur * T] = vH;
+                fvP[(size_t)mcur * T] = vP;
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) aH[e] = aH[e + 1], aP[e] = aP[e + 1];
+            aH[3] = aP[3] = 0.f;
+            ++mcur;
+        };
+        const float *Sb = S + cb + tc, *Pb = perc + cb + tc, *Hb = harm + cb + tc;
+        const float *hrow = hs + tc * KP;
+        for (int k0 = kbeg; k0 < kend; k0 += kWalkBatch) {
+            float sv[kWalkBatch], pv[kWalkBatch], hv[kWalkBatch];
+            float4 wq[kWalkBatch];
+            int ne[kWalkBatch];
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                const int kk = min(k0 + u, K - 1);
+                sv[u] = Sb[(size_t)kk * T];
+                pv[u] = Pb[(size_t)kk * T];
+                hv[u] = harm_tmajor ? hrow[kk] : Hb[(size_t)kk * T];
+                const int pi = min(k0 + u, kend - 1) - kbeg;  // wave-uniform: scalar loads
+                wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
+                ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                if (k0 + u >= kend) break;
+                for (int i = 0; i < ne[u]; ++i) emit_first();  // wave-uniform trip count
+                float H, P;
+                hpss_masks_fast(sv[u], hv[u], pv[u], H, P);
+                aH[0] = fmaf(wq[u].x, H, aH[0]), aP[0] = fmaf(wq[u].x, P, aP[0]);
+                aH[1] = fmaf(wq[u].y, H, aH[1]), aP[1] = fmaf(wq[u].y, P, aP[1]);
+                aH[2] = fmaf(wq[u].z, H, aH[2]), aP[2] = fmaf(wq[u].z, P, aP[2]);
+                aH[3] = fmaf(wq[u].w, H, aH[3]), aP[3] = fmaf(wq[u].w, P, aP[3]);
+            }
+        }
+        while (mcur < m1) emit_first();
+    }
+    if (log_db) {
+        int kH = ordered_key(mxH), kP = ordered_key(mxP);
+        for (int off = 32; off > 0; off >>= 1) {
+            kH = max(kH, __shfl_xor(kH, off));
+            kP = max(kP, __shfl_xor(kP, off));
+        }
+        if (lane == 0) smax[wave] = kH, smax[16 + wave] = kP;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int a = smax[0], c = smax[16];
+            for (int q = 1; q < nw; ++q) a = max(a, smax[q]), c = max(c, smax[16 + q]);
+            atomicMax(&maxkeys[2 * b], a);
+            atomicMax(&maxkeys[2 * b + 1], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // fused fast path, kernel 2: one workgroup per (clip, half): top_db clip (written back: the final
 // featuregram) -> StandardScaler per row -> time-major patches (B*nP, W, 2*rows) for the TCN.
 // ---------------------------------------------------------------------------------------------------
@@ -397,16 +522,32 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     const int K = c->K, rows = c->feat_rows;
     if (c->n_mels > smh_feat::kMaxMels || c->mel_nnz > smh_feat::kMaxMelNnz)
         return smh::set_error(SMH_E_INVALID, "mel filterbank too large for the fused kernel (n_mels=%d nnz=%d)", c->n_mels, c->mel_nnz);
-    // frame slabs: split T evenly into pieces of <= 64 frames (T=98 -> 2 x 49)
-    const int nslab = (T + 63) / 64;
-    const int TS = (T + nslab - 1) / nslab;
-    const size_t lds = harm_tmajor ? sizeof(float) * (size_t)TS * (K | 1) : 0;
-    if (lds > 150 * 1024) return smh::set_error(SMH_E_INVALID, "K=%d too large for the feature kernel", K);
     if (c->cfg.log_db) {
         hipLaunchKernelGGL(fill_int_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, maxkeys, 2 * B, (int)0x80000000);
         int rc = smh::launch_status("fill_int_kernel");
         if (rc) return rc;
     }
+    // bin-walk kernel: one workgroup per clip (SMH_FEAT_TAPS=1 forces the per-tap kernel below)
+    const size_t lds_walk = sizeof(float) * (harm_tmajor ? (size_t)T * (K | 1) : 0) + 128;
+    const int walk_waves = c->feat_nseg * ((T + 63) / 64);
+    if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !getenv("SMH_FEAT_TAPS")) {
+        FeatPlan fp;
+        fp.nseg = c->feat_nseg;
+        for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
+            fp.m0[i] = c->feat_m0[i], fp.m1[i] = c->feat_m1[i], fp.kbeg[i] = c->feat_kbeg[i], fp.kend[i] = c->feat_kend[i],
+            fp.off[i] = c->feat_off[i];
+        fp.plan = c->d_feat_plan;
+        const int nwaves = std::min(16, walk_waves);
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
+        hipLaunchKernelGGL(hp_feat_walk_kernel, dim3(B), dim3(64 * nwaves), lds_walk, st, fp, c->cfg.log_db, S, harm, perc,
+                           harm_tmajor, K, T, rows, fv, maxkeys);
+        return smh::launch_status("hp_feat_walk_kernel");
+    }
+    // frame slabs: split T evenly into pieces of <= 64 frames (T=98 -> 2 x 49)
+    const int nslab = (T + 63) / 64;
+    const int TS = (T + nslab - 1) / nslab;
+    const size_t lds = harm_tmajor ? sizeof(float) * (size_t)TS * (K | 1) : 0;
+    if (lds > 150 * 1024) return smh::set_error(SMH_E_INVALID, "K=%d too large for the feature kernel", K);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hp_feat_kernel, dim3((T + TS - 1) / TS, B), dim3(kFeatThreads), lds, st, mel_table(c), c->cfg.log_db, S,
                        harm, perc, harm_tmajor, K, T, TS, rows, fv, maxkeys);
