@@ -1,6 +1,7 @@
 // Context (constant tables), error reporting and the integer contracts of the hot path.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "smh_common.h"
@@ -187,7 +188,9 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
     c->mel_nnz = (int)mw.size();
     std::vector<float> plan;
     {   // plan of the bin-walk feature kernel
-        const int R = c->feat_rows, NS = smh_ctx::kMaxFeatSegs;
+        const int R = c->feat_rows;
+        int NS = 4;  // measured best of 3..8 at K = 201, T = 98 (tools/gpu/feat_segs.sh)
+        if (const char *ev = getenv("SMH_FEAT_SEGS")) NS = std::max(1, std::min(atoi(ev), (int)smh_ctx::kMaxFeatSegs));  // tuning
         std::vector<int> st(R), en(R);
         for (int i = 0; i < R; ++i) {
             st[i] = c->n_mels > 0 ? mstart[i] : i;
@@ -195,7 +198,7 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
         }
         auto weight = [&](int m, int k) { return c->n_mels > 0 ? mw[moff[m] + (k - st[m])] : 1.0f; };
         bool ok = true;
-        int bound[NS + 1];
+        int bound[smh_ctx::kMaxFeatSegs + 1];
         bound[0] = 0;
         for (int sgm = 1; sgm < NS; ++sgm) {  // boundaries where the filter start crosses sgm/NS of the bins
             int m = bound[sgm - 1];
