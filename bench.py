@@ -195,7 +195,7 @@ def main():
         roof = {"kernel": "tcn_trunk_kernel+heads_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic(["model"]) if B == 1024 else None}
     else:
-        kn = {"stft": "stft_mag_kernel", "median": "hpss_median_split_kernel", "features": "hp_feat_kernel+std_patch_kernel"}[dominant]
+        kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel", "features": "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
         roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dominant]["frac"],
                 "traffic": traffic({"stft": ["stft"], "median": ["median"], "features": ["hp_feat", "std_patch"]}[dominant]) if B == 1024 else None}

@@ -476,6 +476,10 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     int G = N / 256;
     if (G < 1) G = 1;
     if (G > gmax) G = gmax;
+    if (const char *ev = getenv("SMH_TCN_G")) {  // tuning only (tools/tune_model.py)
+        const int g = atoi(ev);
+        if (g >= 1 && g <= gmax) G = g;
+    }
     a.G = G;
     int GRP = ((G * T + 15) / 16) * 16;
     if (GRP * SX < 2 * kMaxG * kPS) GRP = (2 * kMaxG * kPS + SX - 1) / SX;  // the head scratch lives in one buffer

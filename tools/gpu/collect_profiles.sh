@@ -11,7 +11,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST
 python3 - "$R" <<'PY'
 import csv, glob, json, collections, sys
 R = sys.argv[1]
-short = {"stft_mag_kernel": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat_kernel": "hp_feat", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
+short = {"stft": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat": "hp_feat", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
 def key(name):
     for k, v in short.items():
         if k in name: return v
@@ -39,5 +39,5 @@ json.dump(out, open("gpurun_out/prof/final/%s_pmc_summary.json" % R, "w"), inden
 print(json.dumps(out, indent=1, sort_keys=True))
 PY
 cp $(ls gpurun_out/prof/final/trace/*/*_kernel_stats.csv | head -1) gpurun_out/prof/final/${R}_kernel_stats.csv
-tail -1 gpurun_out/prof/final/bench_trace.log > gpurun_out/prof/final/${R}_bench_under_rocprof.json
+grep "^{\"metric\"" gpurun_out/prof/final/bench_trace.log | tail -1 > gpurun_out/prof/final/${R}_bench_under_rocprof.json
 exit 0
