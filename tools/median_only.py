@@ -10,13 +10,14 @@ from sm_hpss_mtl_amd.synth import synth_clips
 B = int(os.environ.get("B", 1024))
 lh, lp = int(os.environ.get("LH", 17)), int(os.environ.get("LP", 17))
 iters = int(os.environ.get("ITERS", 20))
+layout = int(os.environ.get("LAYOUT", 1))
 fe = Frontend(FrontendConfig(l_harm=lh, l_perc=lp))
 audio = torch.from_numpy(np.tile(synth_clips(64, seed=1), (B // 64, 1))).cuda()
 S = fe.stft_mag(audio)
 harm, perc = torch.empty_like(S), torch.empty_like(S)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-run = lambda: _lib.check(fe.lib.smh_hpss_median_ex_f32(fe._h, p(S), B, fe.K, S.shape[2], lh, lp, p(harm), p(perc), 1, st))
+run = lambda: _lib.check(fe.lib.smh_hpss_median_ex_f32(fe._h, p(S), B, fe.K, S.shape[2], lh, lp, p(harm), p(perc), layout, st))
 for _ in range(3):
     run()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,4 +27,4 @@ for _ in range(iters):
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / iters
-print("(%d,%d) B=%d: %.4f ms -> %.1f%% of 8 TB/s" % (lh, lp, B, ms, 100 * 3 * 201 * 98 * 4 * B / (ms * 1e-3) / 8e12), flush=True)
+print("layout=%d " % layout + "(%d,%d) B=%d: %.4f ms -> %.1f%% of 8 TB/s" % (lh, lp, B, ms, 100 * 3 * 201 * 98 * 4 * B / (ms * 1e-3) / 8e12), flush=True)
