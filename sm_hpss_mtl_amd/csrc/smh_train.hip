@@ -22,9 +22,9 @@ namespace {
 constexpr float kKerasEps = 1e-7f;
 constexpr float kBnMomentum = 0.99f;
 constexpr float kL2 = 0.01f;
-constexpr int kBG = 2;        // patches per workgroup in the backward kernel
+constexpr int kBG = 1;        // patches per workgroup in the backward kernel
 constexpr int kBS = 33;       // LDS row stride (floats) of the backward buffers
-constexpr int kBThreads = 512;
+constexpr int kBThreads = 1024;
 
 struct HeadsArgs {
     int N, D, NH, n_classes, n_heads, out_dim;
@@ -202,7 +202,11 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
     float *G = sm, *Xs = G + (size_t)RP * kBS, *U = Xs + (size_t)RP * kBS, *Y = U + (size_t)RP * kBS;
     float *W1 = Y + (size_t)RP * kBS;       // [3][32][32]
     float *W2 = W1 + 3 * C * C;             // [32][32]
-    float *B1 = W2 + C * C;                 // [32]
+    // transposed copies for the two phases whose lanes run over the INPUT channel: W1T[tap][co][c], W2T[co][c]
+    // (reading W[c*32 + co] with 32 lanes over c is a 32-way LDS bank conflict: it was 60 % of the kernel's time)
+    float *W1T = W2 + C * C;                // [3][32][32]
+    float *W2T = W1T + 3 * C * C;           // [32][32]
+    float *B1 = W2T + C * C;                // [32]
     float *rowm = B1 + C;                   // per row: m
     float *rowmx = rowm + RP;               // per row: max
     float *dps = rowmx + RP;                // [kBG][kPS] d loss / d pre
@@ -246,8 +250,17 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
             const int g = R / T, t = R - g * T;
             Xs[R * kBS + c] = acts[(((size_t)(n0 + g) * nslot + blk) * T + t) * C + c];
         }
-        for (int i = tid; i < 3 * C * C; i += nt) W1[i] = flatw[o_k1 + i];
-        for (int i = tid; i < C * C; i += nt) W2[i] = flatw[o_k2 + i];
+        for (int i = tid; i < 3 * C * C; i += nt) {
+            const float v = flatw[o_k1 + i];
+            W1[i] = v;
+            const int tap = i / (C * C), c = (i / C) % C, co = i % C;
+            W1T[(tap * C + co) * C + c] = v;
+        }
+        for (int i = tid; i < C * C; i += nt) {
+            const float v = flatw[o_k2 + i];
+            W2[i] = v;
+            W2T[(i % C) * C + i / C] = v;
+        }
         if (tid < C) B1[tid] = flatw[o_b1 + tid];
         __syncthreads();
         // recompute u = conv_d(x) + b1
@@ -295,10 +308,10 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
         for (int i = tid; i < rows * C; i += nt) {
             const int R = i / C, c = i - R * C;
             const float *gr = G + R * kBS;
-            const float *w = W2 + c * C;
+            const float *w = W2T + c;
             float dyn = 0.f;
 #pragma unroll 8
-            for (int co = 0; co < C; ++co) dyn = fmaf(gr[co], w[co], dyn);
+            for (int co = 0; co < C; ++co) dyn = fmaf(gr[co], w[co * C], dyn);
             const float mask = drop ? drop[((size_t)(n0 + R / T) * a.n_blocks + blk) * C + c] : 1.0f;
             dyn *= mask;
             const float u = U[R * kBS + c];
@@ -339,9 +352,9 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
                 const int off = (tap - 1) * d;
                 if (t - off < 0 || t - off >= T) continue;
                 const float *dur = U + (R - off) * kBS;
-                const float *w = W1 + tap * C * C + c * C;
+                const float *w = W1T + tap * C * C + c;
 #pragma unroll 8
-                for (int co = 0; co < C; ++co) acc = fmaf(dur[co], w[co], acc);
+                for (int co = 0; co < C; ++co) acc = fmaf(dur[co], w[co * C], acc);
             }
             G[R * kBS + c] = acc;
         }
@@ -507,7 +520,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
     const int RP = kBG * ba.T;
-    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 3 * C * C + C * C + C + 3 * RP + kBG * kPS);
+    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel", ba.T);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tcn_backward_kernel, dim3((N + kBG - 1) / kBG), dim3(kBThreads), lds, st, ba, d_x, m->d_flat,

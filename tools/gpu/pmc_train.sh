@@ -1,0 +1,22 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+rm -rf gpurun_out/prof/kt && mkdir -p gpurun_out/prof/kt
+pass() { n=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/prof/kt/$n -- python3 tools/time_train.py > gpurun_out/prof/kt/$n.log 2>&1; echo "$n rc=$?"; }
+pass p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+pass p2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH
+python3 - <<'PY'
+import csv, glob, collections
+for d in ("p1", "p2"):
+    fs = glob.glob("gpurun_out/prof/kt/%s/*/*_counter_collection.csv" % d)
+    if not fs:
+        print(d, "no csv"); continue
+    agg = collections.defaultdict(list); meta = {}
+    for r in csv.DictReader(open(fs[0])):
+        if "tcn_backward" in r["Kernel_Name"] and r["Grid_Size"] == "24576":
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r.get(k) for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    print(meta)
+    for c, v in sorted(agg.items()):
+        print("%-24s %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY
