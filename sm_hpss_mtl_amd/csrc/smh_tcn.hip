@@ -74,6 +74,7 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
             if (tap != 1 && !side_taps) continue;
             const int off = (tap - 1) * d;
             const bool ok = (t + off >= 0) && (t + off < T);
+            if (tap != 1 && !__any(ok)) continue;  // every row of this tile reads zero padding through this tap
             const float *src = xin + (size_t)(ok ? Rc + off : Rc) * SX + q;
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
