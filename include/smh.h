@@ -248,7 +248,8 @@ float *smh_trainer_grad_ptr(smh_trainer *t);
  *   d_drop_tcn  (N, n_blocks, 32) SpatialDropout1D masks (0 or 1/(1-rate)) or NULL (no dropout)
  *   d_drop_heads (N, n_heads, 16) Dropout(0.4) masks (0 or 1/0.6) or NULL
  *   h_loss_weights: n_heads + 1 host floats in output order (NULL = all 1)
- *   d_losses: n_heads + 3 floats out = [per-head losses..., 3C loss, weighted sum (without the l2 term), 3C accuracy] */
+ *   d_losses: n_heads + 4 floats out = [per-head losses..., 3C loss, weighted sum (without the l2 term), 3C accuracy,
+ *             l2(0.01) penalty of the Dense(16) kernels = the term Keras adds to the reported total] */
 int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
                        const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream);
 /* g = grad * grad_scale (+ l2 term); per-tensor clip to `clipnorm` (<= 0: off); v = momentum*v - lr*g; w += v;

@@ -10,6 +10,7 @@
 // Round-1 scope: CORRECT and device-resident.  The backward kernel recomputes each block from its saved
 // input with plain VALU loops in LDS and accumulates weight gradients with float atomics; moving it onto
 // the MFMA tiling of the forward kernel is the obvious next step.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -180,7 +181,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         }
         losses[nh] = s_loss[nh];
         total += a.lw[nh] * s_loss[nh];
-        losses[nh + 1] = total;           // without the l2 term (added by the host from the weights' norms)
+        losses[nh + 1] = total;           // without the l2 term (losses[nh + 3], l2_penalty_kernel)
         losses[nh + 2] = s_loss[nh + 1];  // 3C accuracy
     }
 }
@@ -374,6 +375,313 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA form of the backward pass (the default).  One workgroup = kMG patches (rows = kMG*T activations rows of 32
+// channels in LDS, stride SX), 8 waves.  Per residual block, last to first, with the block input x re-read from the
+// activations the TRAIN forward saved:
+//   1. per 16-row tile (one wave each): u = conv_d(x) + b1 recomputed with the forward's transposed products
+//      D[channel][time] (48 MFMA), relu / channel-max norm -> y (to LDS), dyn = W2 . g as D[c][time] (16 MFMA, g from
+//      LDS as B operand), the norm / relu backward in registers (same lane owns the same channels of u and dyn)
+//      -> du (to LDS);
+//   2. weight gradients as 16 x 16 output tiles with K = rows: dW2[c][co] = sum_t y[t][c] g[t][co],
+//      dW1[tap][c][co] = sum_t x[t+off][c] du[t][co], biases as products with a ones operand; 20 tile jobs over the
+//      8 waves, results added to the global gradient with hardware float atomics;
+//   3. per tile: g += sum_tap W1[tap] . du[t - off] (48 MFMA), in place.
+// A operands come from LDS copies of the block's canonical kernels (W1 for the recompute, W1T / W2T = input-channel
+// minor for the two transposed products: conflict-free for lanes that run over the row index).
+// The Dense-on-trunk weight gradient (a rank-N update of a D x 51 matrix) is its own kernel without atomics.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMG = 1;
+constexpr int kMThreads = 512;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(kMThreads)
+tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw,
+                         const float *__restrict__ acts, const float *__restrict__ drop, const float *__restrict__ dpre,
+                         float *__restrict__ grad, int RPm) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int T = a.T, nslot = a.n_blocks + 1;
+    const int n0 = blockIdx.x * kMG;
+    const int g_here = min(kMG, a.N - n0);
+    const int rows = g_here * T;
+    const int units = RPm >> 4;
+    float *Xs = sm, *G = Xs + (size_t)RPm * SX, *DU = G + (size_t)RPm * SX, *Y = DU + (size_t)RPm * SX;
+    float *W1 = Y + (size_t)RPm * SX;   // [3][32 cin][32 cout]   (canonical)
+    float *W1T = W1 + 3 * C * C;        // [3][32 cout][32 cin]
+    float *W2T = W1T + 3 * C * C;       // [32 cout][32 cin]
+    float *B1 = W2T + C * C;            // [32]
+    float *dps = B1 + C;                // [kMG][kPS]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int q = lane >> 4, j = lane & 15;
+
+    for (int i = tid; i < 4 * RPm * SX; i += nt) sm[i] = 0.f;  // padded rows stay zero in every buffer
+    for (int i = tid; i < g_here * kPS; i += nt) dps[i] = dpre[(size_t)n0 * kPS + i];
+    __syncthreads();
+    // ---- Dense-on-trunk backward: G = relu'(x) * (dpre @ Wh^T) ------------------------------------------------
+    for (int i = tid; i < rows * C; i += nt) {
+        const int R = i / C, c = i - R * C;
+        const int g = R / T, t = R - g * T;
+        const size_t k = (size_t)t * C + c;
+        const float xpre = acts[(((size_t)(n0 + g) * nslot + a.n_blocks) * T + t) * C + c];
+        float acc = 0.f;
+        const float *dp = dps + g * kPS;
+        for (int o = 0; o < a.n_classes; ++o) acc = fmaf(dp[o], flatw[a.off.c3_k + k * a.n_classes + o], acc);
+        for (int h = 0; h < a.n_heads; ++h) {
+            const float *wr = flatw + a.off.head[h] + k * kHidden;
+#pragma unroll
+            for (int jj = 0; jj < kHidden; ++jj) acc = fmaf(dp[a.n_classes + h * kHidden + jj], wr[jj], acc);
+        }
+        G[R * SX + c] = xpre > 0.f ? acc : 0.f;
+    }
+
+    auto tile_job = [&](const float *Asrc, int a_shift, int mt, const float *Bsrc, int nt_, bool ones, size_t gbase,
+                        bool bias) {
+        // D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[row][k] B[k][col], k = activation row
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < RPm / 4; ++s) {
+            const int kr = 4 * s + q;
+            float av = 1.0f;
+            if (!ones) {
+                const int t = kr % T;  // only rows < `rows` matter: B is zero beyond
+                const int sr = kr + a_shift;
+                const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
+                av = ok ? Asrc[sr * SX + 16 * mt + j] : 0.f;
+            }
+            const float bv = Bsrc[kr * SX + 16 * nt_ + j];
+            acc = mfma4(av, bv, acc);
+        }
+        if (bias) {
+            if (q == 0) atomicAdd(&grad[gbase + 16 * nt_ + j], acc[0]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&grad[gbase + (size_t)(16 * mt + 4 * q + r) * C + 16 * nt_ + j], acc[r]);
+        }
+    };
+
+    // ---- residual blocks, last to first --------------------------------------------------------------------------
+    for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
+        const int d = 1 << (blk % a.n_dil);
+        const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+        const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
+        __syncthreads();  // previous block finished with Xs / W*
+        for (int i = tid; i < rows * (C / 4); i += nt) {
+            const int R = i >> 3, c4 = (i & 7) * 4;
+            const int g = R / T, t = R - g * T;
+            *reinterpret_cast<f32x4 *>(Xs + (size_t)R * SX + c4) =
+                *reinterpret_cast<const f32x4 *>(acts + (((size_t)(n0 + g) * nslot + blk) * T + t) * C + c4);
+        }
+        for (int i = tid; i < 3 * C * C; i += nt) {
+            const float v = flatw[o_k1 + i];
+            W1[i] = v;
+            const int tap = i / (C * C), c = (i / C) % C, co = i % C;
+            W1T[(tap * C + co) * C + c] = v;
+        }
+        for (int i = tid; i < C * C; i += nt) W2T[(i % C) * C + i / C] = flatw[o_k2 + i];
+        if (tid < C) B1[tid] = flatw[o_b1 + tid];
+        __syncthreads();
+        // ---- phase 1: recompute, norm, dyn, norm backward -> Y, DU ---------------------------------------------
+        for (int u = wave; u < units; u += nw) {
+            const int R = 16 * u + j;
+            const bool live = R < rows;
+            const int Rc = min(R, rows - 1);
+            const int t = Rc % T;
+            f32x4 acc0 = *reinterpret_cast<const f32x4 *>(B1 + 4 * q), acc1 = *reinterpret_cast<const f32x4 *>(B1 + 16 + 4 * q);
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int off = (tap - 1) * d;
+                const bool ok = (t + off >= 0) && (t + off < T);
+                if (tap != 1 && !__any(ok)) continue;
+                const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + q;
+                const float *wa = W1 + (size_t)(tap * C + q) * C + j;  // W1[tap][cin = 4 s8 + q][cout = j (+16)]
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    float bv = src[4 * s8];
+                    bv = ok ? bv : 0.f;
+                    acc0 = mfma4(wa[(4 * s8) * C], bv, acc0);
+                    acc1 = mfma4(wa[(4 * s8) * C + 16], bv, acc1);
+                }
+            }
+            float r0[4], r1[4], mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                r0[r] = fmaxf(acc0[r], 0.f), r1[r] = fmaxf(acc1[r], 0.f);
+                mx = fmaxf(mx, fmaxf(r0[r], r1[r]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m = mx + kNormEps;
+            f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
+            if (drop) {
+                const float *dp = drop + ((size_t)(n0 + Rc / T) * a.n_blocks + blk) * C + 4 * q;
+                dm0 = *reinterpret_cast<const f32x4 *>(dp);
+                dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
+            }
+            f32x4 y0, y1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y0[r] = live ? r0[r] / m * dm0[r] : 0.f;
+                y1[r] = live ? r1[r] / m * dm1[r] : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(Y + (size_t)R * SX + 4 * q) = y0;
+            *reinterpret_cast<f32x4 *>(Y + (size_t)R * SX + 16 + 4 * q) = y1;
+            // dyn[c][time] = sum_co W2[c][co] g[time][co]
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const float *gs = G + (size_t)Rc * SX + q;
+                const float *wa = W2T + (size_t)q * C + j;  // W2T[co = 4 s + q][c = j (+16)]
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const float bv = live ? gs[4 * s8] : 0.f;
+                    d0 = mfma4(wa[(4 * s8) * C], bv, d0);
+                    d1 = mfma4(wa[(4 * s8) * C + 16], bv, d1);
+                }
+            }
+            float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d0[r] *= dm0[r], d1[r] *= dm1[r];
+                s1 = fmaf(d0[r], r0[r], s1);
+                s1 = fmaf(d1[r], r1[r], s1);
+                cnt += (r0[r] == mx ? 1.f : 0.f) + (r1[r] == mx ? 1.f : 0.f);
+            }
+            s1 += __shfl_xor(s1, 16), cnt += __shfl_xor(cnt, 16);
+            s1 += __shfl_xor(s1, 32), cnt += __shfl_xor(cnt, 32);
+            const float corr = s1 / (m * m) / cnt;
+            f32x4 du0, du1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a0 = d0[r] / m, a1 = d1[r] / m;
+                if (r0[r] == mx && r0[r] > 0.f) a0 -= corr;
+                if (r1[r] == mx && r1[r] > 0.f) a1 -= corr;
+                du0[r] = (live && acc0[r] > 0.f) ? a0 : 0.f;
+                du1[r] = (live && acc1[r] > 0.f) ? a1 : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(DU + (size_t)R * SX + 4 * q) = du0;
+            *reinterpret_cast<f32x4 *>(DU + (size_t)R * SX + 16 + 4 * q) = du1;
+        }
+        __syncthreads();
+        // ---- phase 2: weight gradients (20 tile jobs) ------------------------------------------------------------
+        for (int job = wave; job < 20; job += nw) {
+            if (job < 4) {
+                tile_job(Y, 0, job >> 1, G, job & 1, false, o_k2, false);  // dW2[c][co]
+            } else if (job < 16) {
+                const int tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
+                tile_job(Xs, (tap - 1) * d, mt, DU, nt_, false, o_k1 + (size_t)tap * C * C, false);  // dW1[tap][c][co]
+            } else if (job < 18) {
+                tile_job(nullptr, 0, 0, G, job - 16, true, o_b2, true);   // db2[co] = sum_t g
+            } else {
+                tile_job(nullptr, 0, 0, DU, job - 18, true, o_b1, true);  // db1[co] = sum_t du
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: g[time][c] += sum_tap sum_co W1[tap][c][co] du[time - off][co] ---------------------------------
+        for (int u = wave; u < units; u += nw) {
+            const int R = 16 * u + j;
+            if (16 * u >= rows) continue;
+            const bool live = R < rows;
+            const int Rc = min(R, rows - 1);
+            const int t = Rc % T;
+            f32x4 g0 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 4 * q);
+            f32x4 g1 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 16 + 4 * q);
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int off = (tap - 1) * d;
+                const bool ok = (t - off >= 0) && (t - off < T);
+                if (tap != 1 && !__any(ok)) continue;
+                const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + q;
+                const float *wa = W1T + (size_t)(tap * C + q) * C + j;  // W1T[tap][co = 4 s8 + q][c = j (+16)]
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    float bv = src[4 * s8];
+                    bv = ok ? bv : 0.f;
+                    g0 = mfma4(wa[(4 * s8) * C], bv, g0);
+                    g1 = mfma4(wa[(4 * s8) * C + 16], bv, g1);
+                }
+            }
+            if (live) {
+                *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 4 * q) = g0;
+                *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 16 + 4 * q) = g1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- initial Conv1D(32,1): dW0[f][c] = sum_R x[R][f] g[R][c] ; db0[c] = sum_R g[R][c] -----------------------------
+    const int fmt = (a.F + 15) >> 4;
+    for (int job = wave; job < fmt * 2 + 2; job += nw) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool bias = job >= fmt * 2;
+        const int mt = bias ? 0 : job >> 1, nt_ = bias ? job - fmt * 2 : job & 1;
+        const int f = 16 * mt + j;
+        for (int s = 0; s < RPm / 4; ++s) {
+            const int kr = 4 * s + q;
+            float av = 1.0f;
+            if (!bias) av = (kr < rows && f < a.F) ? X[((size_t)n0 * T + kr) * a.F + f] : 0.f;
+            acc = mfma4(av, G[(size_t)kr * SX + 16 * nt_ + j], acc);
+        }
+        if (bias) {
+            if (q == 0) atomicAdd(&grad[a.off.w0_b + 16 * nt_ + j], acc[0]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ff = 16 * mt + 4 * q + r;
+                if (ff < a.F) atomicAdd(&grad[a.off.w0_k + (size_t)ff * C + 16 * nt_ + j], acc[r]);
+            }
+        }
+    }
+}
+
+// dWh[k][o] = sum_b relu(x_b)[k] dpre[b][o] for the '3C' kernel and the Dense(16) kernel of every head: one thread per
+// (k, output group) and batch slice of kDwhSlice patches (grid.y); slices are combined with hardware float atomics.
+constexpr int kDwhSlice = 16;
+__global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const float *__restrict__ dpre,
+                           float *__restrict__ grad) {
+    const int ngroups = 1 + a.n_heads;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.D * ngroups) return;
+    const int grp = i / a.D, k = i - grp * a.D;  // k fastest: coalesced reads of the activations
+    const int nslot = a.n_blocks + 1;
+    const int ocount = grp == 0 ? a.n_classes : kHidden;
+    const int o0 = grp == 0 ? 0 : a.n_classes + (grp - 1) * kHidden;
+    const int b0 = blockIdx.y * kDwhSlice, b1 = min(a.N, b0 + kDwhSlice);
+    float acc[kHidden];
+#pragma unroll
+    for (int o = 0; o < kHidden; ++o) acc[o] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float fl = fmaxf(acts[((size_t)b * nslot + a.n_blocks) * a.D + k], 0.f);
+        const float *dp = dpre + (size_t)b * kPS + o0;
+#pragma unroll
+        for (int o = 0; o < kHidden; ++o)
+            if (o < ocount) acc[o] = fmaf(fl, dp[o], acc[o]);
+    }
+    float *g = grad + (grp == 0 ? a.off.c3_k + (size_t)k * a.n_classes : a.off.head[grp - 1] + (size_t)k * kHidden);
+#pragma unroll
+    for (int o = 0; o < kHidden; ++o)
+        if (o < ocount) atomicAdd(&g[o], acc[o]);
+}
+
+// l2(0.01) penalty of the Dense(16) kernels (the term Keras adds to the reported total loss), from the weights the
+// step ran with: one workgroup, f64 accumulation.
+__global__ void __launch_bounds__(1024) l2_penalty_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (int h = 0; h < a.n_heads; ++h) {
+        const float *w = flatw + a.off.head[h];
+        for (int i = threadIdx.x; i < a.D * kHidden; i += blockDim.x) s += (double)w[i] * (double)w[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+        out[0] = (float)((double)kL2 * t);
+    }
+}
+
 struct Segment {
     unsigned off, size;
     int kind;  // 0 plain, 1 l2-regularised Dense(16) kernel, 2 BN moving_mean, 3 BN moving_variance
@@ -519,6 +827,23 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     BwdArgs ba;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
+    hipLaunchKernelGGL(l2_penalty_kernel, dim3(1), dim3(1024), 0, st, ba, m->d_flat, d_losses + m->n_heads + 3);
+    rc = smh::launch_status("l2_penalty_kernel");
+    if (rc) return rc;
+    // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
+    const int RPm = ((kMG * ba.T + 15) / 16) * 16;
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 2 * 3 * C * C + C * C + C + kMG * kPS);
+    if (lds_m <= 156 * 1024 && !getenv("SMH_TRAIN_VALU")) {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        hipLaunchKernelGGL(tcn_backward_mfma_kernel, dim3((N + kMG - 1) / kMG), dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat,
+                           t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad, RPm);
+        rc = smh::launch_status("tcn_backward_mfma_kernel");
+        if (rc) return rc;
+        const int nthr = ba.D * (1 + ba.n_heads);
+        hipLaunchKernelGGL(dwh_kernel, dim3((nthr + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice), dim3(256), 0, st, ba, t->d_acts,
+                           t->d_dpre, t->d_grad);
+        return smh::launch_status("dwh_kernel");
+    }
     const int RP = kBG * ba.T;
     const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel", ba.T);

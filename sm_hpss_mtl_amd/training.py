@@ -117,14 +117,14 @@ class TrainingMixin:
         if isinstance(drop_heads, str):
             keep = 1.0 - HEAD_DROPOUT
             drop_heads = (torch.rand((n, n_heads, 16), device="cuda", generator=self._rng) < keep).float() / keep
-        losses = torch.empty(n_heads + 3, dtype=torch.float32, device="cuda")
+        losses = torch.empty(n_heads + 4, dtype=torch.float32, device="cuda")
         p = lambda t: None if t is None else C.c_void_p(t.contiguous().data_ptr())  # noqa: E731
         _lib.check(self.lib.smh_train_step_f32(tr, p(x), p(yt), n, p(drop_tcn), p(drop_heads), self._loss_weight_array(),
                                                p(losses), _cur_stream()), "smh_train_step_f32")
         if apply:
             self.apply_gradients()
         lv = losses.cpu().numpy()
-        reg = self._l2_penalty()
+        reg = float(lv[n_heads + 3])  # l2 penalty of the weights this step ran with, computed on the device
         # Keras order: total loss, one loss per output, then the metric
         return [float(lv[n_heads + 1] + reg)] + [float(v) for v in lv[: n_heads + 1]] + [float(lv[n_heads + 2])]
 
