@@ -35,7 +35,20 @@ struct HeadsArgs {
     size_t goff_c3b;              // canonical offset of the 3C bias
 };
 
-// Single workgroup: the batch-statistics part of the network is tiny (N x 51 values).
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the wave, then ONE LDS atomic per wave (all lanes must call it; idle lanes pass 0)
+__device__ __forceinline__ void wave_add(float *addr, float v) {
+    v = wave_sum_f(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(addr, v);
+}
+
+// Single workgroup: the batch-statistics part of the network is tiny (N x 51 values).  Every reduction over the
+// batch is spread over the lanes (16 lanes per hidden unit for the statistics; one head at a time with wave-level
+// sums for the gradients of the small tensors) -- a thread looping over the whole batch was 60 % of this kernel.
 __global__ void __launch_bounds__(1024)
 heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__restrict__ y, const float *__restrict__ hp,
                    const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
@@ -49,27 +62,37 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     if (tid < kMaxHeads * 3) s_dbo[tid] = 0.f;
     if (tid < kMaxHeads + 2) s_loss[tid] = 0.f;
     if (tid < 8) s_db3[tid] = 0.f;
-    // A: batch statistics of every hidden unit (population variance, two passes)
-    if (tid < NJ) {
+    // A: batch statistics of every hidden unit (population variance, two passes): 16 lanes per unit
+    {
+        const int j = tid >> 4, sub = tid & 15;
+        const bool on = j < NJ;
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s += pre[(size_t)n * kPS + ncls + tid];
+        if (on)
+            for (int n = sub; n < N; n += 16) s += pre[(size_t)n * kPS + ncls + j];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / (float)N;
         float q = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float d = pre[(size_t)n * kPS + ncls + tid] - mean;
-            q += d * d;
+        if (on)
+            for (int n = sub; n < N; n += 16) {
+                const float d = pre[(size_t)n * kPS + ncls + j] - mean;
+                q += d * d;
+            }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (on && sub == 0) {
+            const float var = q / (float)N;
+            s_mean[j] = mean;
+            s_inv[j] = 1.0f / sqrtf(var + kBnEps);
+            const int h = j / kHidden, i = j % kHidden;
+            bnstat[h * 32 + i] = mean;
+            bnstat[h * 32 + 16 + i] = var;
         }
-        const float var = q / (float)N;
-        s_mean[tid] = mean;
-        s_inv[tid] = 1.0f / sqrtf(var + kBnEps);
-        const int h = tid / kHidden, i = tid % kHidden;
-        bnstat[h * 32 + i] = mean;
-        bnstat[h * 32 + 16 + i] = var;
     }
     __syncthreads();
-    // B: per (sample, head): forward through BN / relu / dropout / output Dense, loss, and gradients
-    for (int it = tid; it < N * nh; it += nt) {
-        const int n = it / nh, h = it - n * nh;
+    // B: one head at a time, lanes over the samples: forward through BN / relu / dropout / output Dense, loss,
+    // gradients; sums over the batch are wave-reduced before they touch LDS
+    for (int h = 0; h < nh; ++h) {
         const float *ph = hp;
         int col = 0;
         for (int k = 0; k < h; ++k) {
@@ -79,52 +102,57 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         const float *gamma = ph, *beta = ph + 16, *wo = ph + 64;
         const int od = a.head_odim[h];
         const float *bo = wo + kHidden * od;
-        float xh[kHidden], bn[kHidden], ad[kHidden], dm[kHidden];
-        float zo[3] = {0.f, 0.f, 0.f};
-        for (int c = 0; c < od; ++c) zo[c] = bo[c];
+        for (int n0 = 0; n0 < N; n0 += nt) {
+            const int n = n0 + tid;
+            const bool on = n < N;
+            const int nc = on ? n : N - 1;
+            float xh[kHidden], bn[kHidden], ad[kHidden], dm[kHidden];
+            float zo[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < od; ++c) zo[c] = bo[c];
 #pragma unroll
-        for (int i = 0; i < kHidden; ++i) {
-            const int j = h * kHidden + i;
-            xh[i] = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
-            bn[i] = xh[i] * gamma[i] + beta[i];
-            dm[i] = drop ? drop[((size_t)n * nh + h) * kHidden + i] : 1.0f;
-            ad[i] = fmaxf(bn[i], 0.f) * dm[i];
-            for (int c = 0; c < od; ++c) zo[c] = fmaf(ad[i], wo[i * od + c], zo[c]);
-        }
-        float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f;
-        for (int c = 0; c < od; ++c) {
-            const float t = y[(size_t)n * a.out_dim + col + c];
-            if (a.head_sigmoid[h]) {
-                const float o = 1.0f / (1.0f + expf(-zo[c]));
-                const float oc = fminf(fmaxf(o, kKerasEps), 1.0f - kKerasEps);
-                lsum += -(t * logf(oc + kKerasEps) + (1.0f - t) * logf(1.0f - oc + kKerasEps));
-                const bool inside = (o > kKerasEps) && (o < 1.0f - kKerasEps);
-                const float doc = -(t / (oc + kKerasEps) - (1.0f - t) / (1.0f - oc + kKerasEps)) / (float)(N * od);
-                dzo[c] = inside ? doc * o * (1.0f - o) : 0.f;
-            } else {
-                const float d = zo[c] - t;
-                lsum += d * d;
-                dzo[c] = 2.0f * d / (float)(N * od);
+            for (int i = 0; i < kHidden; ++i) {
+                const int j = h * kHidden + i;
+                xh[i] = (pre[(size_t)nc * kPS + ncls + j] - s_mean[j]) * s_inv[j];
+                bn[i] = xh[i] * gamma[i] + beta[i];
+                dm[i] = drop ? drop[((size_t)nc * nh + h) * kHidden + i] : 1.0f;
+                ad[i] = fmaxf(bn[i], 0.f) * dm[i];
+                for (int c = 0; c < od; ++c) zo[c] = fmaf(ad[i], wo[i * od + c], zo[c]);
             }
-            dzo[c] *= a.lw[h];
-            atomicAdd(&s_dbo[h * 3 + c], dzo[c]);
-        }
-        atomicAdd(&s_loss[h], lsum / (float)(N * od));
-#pragma unroll
-        for (int i = 0; i < kHidden; ++i) {
-            const int j = h * kHidden + i;
-            float da = 0.f;
+            float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f;
             for (int c = 0; c < od; ++c) {
-                da = fmaf(dzo[c], wo[i * od + c], da);
-                atomicAdd(&s_dwo[(h * kHidden + i) * 3 + c], ad[i] * dzo[c]);
+                const float t = y[(size_t)nc * a.out_dim + col + c];
+                if (a.head_sigmoid[h]) {
+                    const float o = 1.0f / (1.0f + expf(-zo[c]));
+                    const float oc = fminf(fmaxf(o, kKerasEps), 1.0f - kKerasEps);
+                    lsum += -(t * logf(oc + kKerasEps) + (1.0f - t) * logf(1.0f - oc + kKerasEps));
+                    const bool inside = (o > kKerasEps) && (o < 1.0f - kKerasEps);
+                    const float doc = -(t / (oc + kKerasEps) - (1.0f - t) / (1.0f - oc + kKerasEps)) / (float)(N * od);
+                    dzo[c] = inside ? doc * o * (1.0f - o) : 0.f;
+                } else {
+                    const float d = zo[c] - t;
+                    lsum += d * d;
+                    dzo[c] = 2.0f * d / (float)(N * od);
+                }
+                dzo[c] = on ? dzo[c] * a.lw[h] : 0.f;
+                wave_add(&s_dbo[h * 3 + c], dzo[c]);
             }
-            const float dbn = bn[i] > 0.f ? da * dm[i] : 0.f;
-            const float dxhat = dbn * gamma[i];
-            dxh[(size_t)n * kPS + j] = dxhat;
-            atomicAdd(&s_dgamma[j], dbn * xh[i]);
-            atomicAdd(&s_dbeta[j], dbn);
-            atomicAdd(&s_sum1[j], dxhat);
-            atomicAdd(&s_sum2[j], dxhat * xh[i]);
+            wave_add(&s_loss[h], on ? lsum / (float)(N * od) : 0.f);
+#pragma unroll
+            for (int i = 0; i < kHidden; ++i) {
+                const int j = h * kHidden + i;
+                float da = 0.f;
+                for (int c = 0; c < od; ++c) {
+                    da = fmaf(dzo[c], wo[i * od + c], da);
+                    wave_add(&s_dwo[(h * kHidden + i) * 3 + c], ad[i] * dzo[c]);
+                }
+                const float dbn = (on && bn[i] > 0.f) ? da * dm[i] : 0.f;
+                const float dxhat = dbn * gamma[i];
+                if (on) dxh[(size_t)n * kPS + j] = dxhat;
+                wave_add(&s_dgamma[j], dbn * xh[i]);
+                wave_add(&s_dbeta[j], dbn);
+                wave_add(&s_sum1[j], dxhat);
+                wave_add(&s_sum2[j], dxhat * xh[i]);
+            }
         }
     }
     __syncthreads();
@@ -136,29 +164,33 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         dpre[(size_t)n * kPS + ncls + j] = d;
         atomicAdd(&s_dbias[j], d);
     }
-    // D: softmax + categorical cross-entropy
-    for (int n = tid; n < N; n += nt) {
+    // D: softmax + categorical cross-entropy (lanes over the samples, wave-reduced sums)
+    for (int n0 = 0; n0 < N; n0 += nt) {
+        const int n = n0 + tid;
+        const bool on = n < N;
+        const int nc = on ? n : N - 1;
         float mx = -INFINITY, p[8], t[8];
-        for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, pre[(size_t)n * kPS + c]);
+        for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, pre[(size_t)nc * kPS + c]);
         float den = 0.f;
-        for (int c = 0; c < ncls; ++c) den += (p[c] = expf(pre[(size_t)n * kPS + c] - mx));
+        for (int c = 0; c < ncls; ++c) den += (p[c] = expf(pre[(size_t)nc * kPS + c] - mx));
         int am = 0, at = 0;
         float l = 0.f;
         for (int c = 0; c < ncls; ++c) {
             p[c] /= den;
-            t[c] = y[(size_t)n * a.out_dim + (a.out_dim - ncls) + c];
+            t[c] = y[(size_t)nc * a.out_dim + (a.out_dim - ncls) + c];
             l -= t[c] * logf(fminf(fmaxf(p[c], kKerasEps), 1.0f - kKerasEps));
             if (p[c] > p[am]) am = c;
             if (t[c] > t[at]) at = c;
         }
         for (int c = 0; c < ncls; ++c) {
-            const float d = (p[c] - t[c]) / (float)N * a.lw[nh];
-            dpre[(size_t)n * kPS + c] = d;
-            atomicAdd(&s_db3[c], d);
+            const float d = on ? (p[c] - t[c]) / (float)N * a.lw[nh] : 0.f;
+            if (on) dpre[(size_t)n * kPS + c] = d;
+            wave_add(&s_db3[c], d);
         }
-        for (int c = ncls + NJ; c < kPS; ++c) dpre[(size_t)n * kPS + c] = 0.f;
-        atomicAdd(&s_loss[nh], l / (float)N);
-        atomicAdd(&s_loss[nh + 1], am == at ? 1.0f / (float)N : 0.f);
+        if (on)
+            for (int c = ncls + NJ; c < kPS; ++c) dpre[(size_t)n * kPS + c] = 0.f;
+        wave_add(&s_loss[nh], on ? l / (float)N : 0.f);
+        wave_add(&s_loss[nh + 1], (on && am == at) ? 1.0f / (float)N : 0.f);
     }
     __syncthreads();
     // E: gradients of the small tensors (this workgroup is their only writer) and the losses
@@ -634,33 +666,26 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     }
 }
 
-// dWh[k][o] = sum_b relu(x_b)[k] dpre[b][o] for the '3C' kernel and the Dense(16) kernel of every head: one thread per
-// (k, output group) and batch slice of kDwhSlice patches (grid.y); slices are combined with hardware float atomics.
+// dWh[k][o] = sum_b relu(x_b)[k] dpre[b][o] for the '3C' kernel (grid.z = 0) and the Dense(16) kernel of every head
+// (grid.z = 1 + h): one thread per element (k, o), o fastest, so the float atomics that combine the batch slices
+// (grid.y, kDwhSlice patches each) hit contiguous addresses -- one lane per row of the matrix was 17x slower.
 constexpr int kDwhSlice = 16;
 __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const float *__restrict__ dpre,
                            float *__restrict__ grad) {
-    const int ngroups = 1 + a.n_heads;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.D * ngroups) return;
-    const int grp = i / a.D, k = i - grp * a.D;  // k fastest: coalesced reads of the activations
-    const int nslot = a.n_blocks + 1;
+    const int grp = blockIdx.z;
     const int ocount = grp == 0 ? a.n_classes : kHidden;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.D * ocount) return;
+    const int k = i / ocount, o = i - k * ocount;
+    const int nslot = a.n_blocks + 1;
     const int o0 = grp == 0 ? 0 : a.n_classes + (grp - 1) * kHidden;
     const int b0 = blockIdx.y * kDwhSlice, b1 = min(a.N, b0 + kDwhSlice);
-    float acc[kHidden];
-#pragma unroll
-    for (int o = 0; o < kHidden; ++o) acc[o] = 0.f;
+    float acc = 0.f;
     for (int b = b0; b < b1; ++b) {
         const float fl = fmaxf(acts[((size_t)b * nslot + a.n_blocks) * a.D + k], 0.f);
-        const float *dp = dpre + (size_t)b * kPS + o0;
-#pragma unroll
-        for (int o = 0; o < kHidden; ++o)
-            if (o < ocount) acc[o] = fmaf(fl, dp[o], acc[o]);
+        acc = fmaf(fl, dpre[(size_t)b * kPS + o0 + o], acc);
     }
-    float *g = grad + (grp == 0 ? a.off.c3_k + (size_t)k * a.n_classes : a.off.head[grp - 1] + (size_t)k * kHidden);
-#pragma unroll
-    for (int o = 0; o < kHidden; ++o)
-        if (o < ocount) atomicAdd(&g[o], acc[o]);
+    atomicAdd(grad + (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + i, acc);
 }
 
 // l2(0.01) penalty of the Dense(16) kernels (the term Keras adds to the reported total loss), from the weights the
@@ -839,9 +864,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
                            t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad, RPm);
         rc = smh::launch_status("tcn_backward_mfma_kernel");
         if (rc) return rc;
-        const int nthr = ba.D * (1 + ba.n_heads);
-        hipLaunchKernelGGL(dwh_kernel, dim3((nthr + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice), dim3(256), 0, st, ba, t->d_acts,
-                           t->d_dpre, t->d_grad);
+        hipLaunchKernelGGL(dwh_kernel, dim3((ba.D * kHidden + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice, 1 + ba.n_heads),
+                           dim3(256), 0, st, ba, t->d_acts, t->d_dpre, t->d_grad);
         return smh::launch_status("dwh_kernel");
     }
     const int RP = kBG * ba.T;
