@@ -473,19 +473,25 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     auto tile_job = [&](const float *Asrc, int a_shift, int mt, const float *Bsrc, int nt_, bool ones, size_t gbase,
                         bool bias) {
         // D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[row][k] B[k][col], k = activation row
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < RPm / 4; ++s) {
-            const int kr = 4 * s + q;
-            float av = 1.0f;
-            if (!ones) {
-                const int t = kr % T;  // only rows < `rows` matter: B is zero beyond
-                const int sr = kr + a_shift;
-                const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
-                av = ok ? Asrc[sr * SX + 16 * mt + j] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: MFMA latency > issue
+        for (int s = 0; s < RPm / 4; s += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kr = 4 * (s + e) + q;
+                av[e] = 1.0f;
+                if (!ones) {
+                    const int t = kr % T;  // only rows < `rows` matter: B is zero beyond
+                    const int sr = kr + a_shift;
+                    const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
+                    av[e] = ok ? Asrc[sr * SX + 16 * mt + j] : 0.f;
+                }
+                bv[e] = (s + e < RPm / 4) ? Bsrc[kr * SX + 16 * nt_ + j] : 0.f;
             }
-            const float bv = Bsrc[kr * SX + 16 * nt_ + j];
-            acc = mfma4(av, bv, acc);
+            acc = mfma4(av[0], bv[0], acc);
+            acc2 = mfma4(av[1], bv[1], acc2);
         }
+        acc += acc2;
         if (bias) {
             if (q == 0) atomicAdd(&grad[gbase + 16 * nt_ + j], acc[0]);
         } else {
@@ -494,27 +500,55 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         }
     };
 
+    // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
+    constexpr int kPfX = (kMG * 80 * (C / 4) + kMThreads - 1) / kMThreads;  // T <= 80 per patch (checked on the host)
+    f32x4 pf_x[kPfX];
+    float pf_w1[6], pf_w2[2], pf_b1 = 0.f;
+    auto prefetch = [&](int blk) {
+        const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+#pragma unroll
+        for (int e = 0; e < kPfX; ++e) {
+            const int i = tid + e * kMThreads;
+            if (i < rows * (C / 4)) {
+                const int R = i >> 3, c4 = (i & 7) * 4;
+                const int g = R / T, t = R - g * T;
+                pf_x[e] = *reinterpret_cast<const f32x4 *>(acts + (((size_t)(n0 + g) * nslot + blk) * T + t) * C + c4);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) pf_w1[e] = flatw[wo + tid + e * kMThreads];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pf_w2[e] = flatw[wo + 3 * C * C + C + tid + e * kMThreads];
+        if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
+    };
+    prefetch(a.n_blocks - 1);
     // ---- residual blocks, last to first --------------------------------------------------------------------------
     for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
         const int d = 1 << (blk % a.n_dil);
         const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
         const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
         __syncthreads();  // previous block finished with Xs / W*
-        for (int i = tid; i < rows * (C / 4); i += nt) {
-            const int R = i >> 3, c4 = (i & 7) * 4;
-            const int g = R / T, t = R - g * T;
-            *reinterpret_cast<f32x4 *>(Xs + (size_t)R * SX + c4) =
-                *reinterpret_cast<const f32x4 *>(acts + (((size_t)(n0 + g) * nslot + blk) * T + t) * C + c4);
+        // this block's inputs were requested during the previous block (registers pf_*); park them in LDS
+#pragma unroll
+        for (int e = 0; e < kPfX; ++e) {
+            const int i = tid + e * kMThreads;
+            if (i < rows * (C / 4)) *reinterpret_cast<f32x4 *>(Xs + (size_t)(i >> 3) * SX + (i & 7) * 4) = pf_x[e];
         }
-        for (int i = tid; i < 3 * C * C; i += nt) {
-            const float v = flatw[o_k1 + i];
-            W1[i] = v;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int i = tid + e * kMThreads;  // 3*C*C = 6 * 512
+            W1[i] = pf_w1[e];
             const int tap = i / (C * C), c = (i / C) % C, co = i % C;
-            W1T[(tap * C + co) * C + c] = v;
+            W1T[(tap * C + co) * C + c] = pf_w1[e];
         }
-        for (int i = tid; i < C * C; i += nt) W2T[(i % C) * C + i / C] = flatw[o_k2 + i];
-        if (tid < C) B1[tid] = flatw[o_b1 + tid];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * kMThreads;  // C*C = 2 * 512
+            W2T[(i % C) * C + i / C] = pf_w2[e];
+        }
+        if (tid < C) B1[tid] = pf_b1;
         __syncthreads();
+        if (blk > 0) prefetch(blk - 1);  // overlaps with the three phases below
         // ---- phase 1: recompute, norm, dyn, norm backward -> Y, DU ---------------------------------------------
         for (int u = wave; u < units; u += nw) {
             const int R = 16 * u + j;
@@ -858,7 +892,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
     const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 2 * 3 * C * C + C * C + C + kMG * kPS);
-    if (lds_m <= 156 * 1024 && !getenv("SMH_TRAIN_VALU")) {
+    if (lds_m <= 156 * 1024 && ba.T <= 80 && !getenv("SMH_TRAIN_VALU")) {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         hipLaunchKernelGGL(tcn_backward_mfma_kernel, dim3((N + kMG - 1) / kMG), dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat,
                            t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad, RPm);
