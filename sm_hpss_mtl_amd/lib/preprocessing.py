@@ -61,6 +61,31 @@ def mix_signals(Xin_sp, Xin_mu, target_dB):
     return normalize_signal(Xin_mix)
 
 
+def removeSilence(Xin, fs, Tw, Ts, alpha=0.025, beta=0.075):
+    """preprocessing.py:21-110, the pure-Python sibling of tools.removeSilence (not on the reference's own call
+    path: load_and_preprocess_signal uses the Cython one).  Same frame / sample markers (computed on the device;
+    the threshold is the Cython function's float32 one), but the output is really shortened: the samples before the
+    first removed run and between runs -- like the reference, the piece after the LAST run is dropped -- and one run
+    is enough to trigger it.  Returns (Xin_silrem, sample_silMarker float64, frame_silMarker int, totalSilDuration)."""
+    from .. import silence as _sil
+    Xin = np.asarray(Xin)
+    frameSize, frameShift = int((Tw * fs) / 1000), int((Ts * fs) / 1000)
+    d = torch.from_numpy(np.ascontiguousarray(Xin, dtype=np.float32)).cuda()
+    energy = _sil.rms(d, frameSize, frameShift)
+    _, _, sm, fm = _sil.remove_silence(d, energy, fs, Tw, Ts, alpha, beta, markers=True)
+    sample_silMarker = sm[0].cpu().numpy().astype(np.float64)
+    frame_silMarker = fm[0].cpu().numpy().astype(int)
+    dd = np.diff(np.concatenate([[1.0], sample_silMarker, [1.0]]))
+    starts, ends = np.where(dd == -1)[0], np.where(dd == 1)[0]
+    totalSilDuration = float(sum((l - k) / fs for k, l in zip(starts, ends)))
+    if len(starts) > 0:
+        pieces = [Xin[:starts[0]]] + [Xin[ends[i - 1]:starts[i]] for i in range(1, len(starts))]
+        Xin_silrem = np.concatenate(pieces) if len(pieces) > 1 else pieces[0]
+    else:
+        Xin_silrem = Xin
+    return Xin_silrem, sample_silMarker, frame_silMarker, totalSilDuration
+
+
 def mix_signals_batch(Xin_sp, Xin_mu, target_dB):
     """Device-resident form of `mix_signals` for float32 CUDA tensors (B, N), (B, N_mu) and B target SMRs."""
     from .. import silence as _sil

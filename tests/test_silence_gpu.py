@@ -201,6 +201,19 @@ def test_mix_signals_vs_oracle(sil, n, nmu):
     assert np.max(np.abs(out2[1] - ofe.mix_signals(sp[1], mu[1], 10.0))) <= 2e-6
 
 
+def test_python_removeSilence_sibling(sil):
+    """lib/preprocessing.py:21-110 (shortened output, the piece after the last run dropped)."""
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    x = osil.normalize_signal(gappy_clip(0))
+    out, sm, fm, tot = pp.removeSilence(x, 16000, 25, 10)
+    _, sm_ref, fm_ref, _ = osil.remove_silence(x, osil.rms(x, 400, 160), 16000, 25, 10)
+    assert np.array_equal(sm, sm_ref.astype(np.float64)) and np.array_equal(fm, fm_ref)
+    runs = osil.silence_runs(fm_ref, len(x), 16000, 25, 10)
+    assert len(runs) == 2
+    ref = np.concatenate([x[:runs[0][0]], x[runs[0][1]:runs[1][0]]])
+    assert np.array_equal(out, ref) and abs(tot - sum((l - k) / 16000 for k, l in runs)) < 1e-12
+
+
 def test_error_behaviour(sil):
     x = dev(np.zeros((2, 1000), np.float32))
     with pytest.raises(ValueError):
