@@ -500,6 +500,15 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
     }
 }
 
+// long clips (featuregram half larger than an LDS tile): top_db clip in place, one workgroup column per array
+__global__ void clip_fv_kernel(float *__restrict__ fv, const int *__restrict__ maxkeys, size_t elems) {
+    const int arr = blockIdx.y;  // 2 * b + half
+    const float thr = key_to_float(maxkeys[arr]) - kTopDb;
+    float *g = fv + (size_t)arr * elems;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = fmaxf(g[i], thr);
+}
+
 __global__ void fill_int_kernel(int *p, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -558,8 +567,32 @@ int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int
                      float *patches, hipStream_t st) {
     const int rows = c->feat_rows;
     const size_t lds = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows);
-    if (lds > 150 * 1024)
-        return smh::set_error(SMH_E_INVALID, "clip of %d frames x %d rows exceeds the LDS tile of the patch kernel", T, rows);
+    if (lds > 150 * 1024) {
+        // long clips: the same three steps as separate streaming kernels over a stream-ordered scratch copy
+        if (B > 32767) return smh::set_error(SMH_E_INVALID, "B=%d too large for the long-clip path; split the batch", B);
+        const size_t half = (size_t)rows * T;
+        if (c->cfg.log_db) {
+            size_t nb = (half + 255) / 256;
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(clip_fv_kernel, dim3((unsigned)nb, 2 * B), dim3(256), 0, st, fv, maxkeys, half);
+            int rc = smh::launch_status("clip_fv_kernel");
+            if (rc) return rc;
+        }
+        if (!patches || nP <= 0) return SMH_OK;
+        float *tmp = nullptr;
+        const size_t n_rows = (size_t)2 * B * rows;
+        SMH_CHECK_HIP(hipMallocAsync((void **)&tmp, n_rows * T * sizeof(float), st));
+        hipLaunchKernelGGL(standardize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, (const float *)fv,
+                           (int)n_rows, T, tmp);
+        const size_t per_clip = (size_t)nP * 2 * rows * W;
+        size_t nb = (per_clip + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(extract_patches_kernel, dim3((unsigned)nb, B), dim3(256), 0, st, (const float *)tmp, 2 * rows, T,
+                           smh_tiled_frames(T, W), W, shift, nP, 1, patches);
+        int rc = smh::launch_status("long-clip standardise / patch kernels");
+        SMH_CHECK_HIP(hipFreeAsync(tmp, st));
+        return rc;
+    }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(std_patch_kernel, dim3(2, B), dim3(kPatchThreads), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
                        smh_tiled_frames(T, W), W, shift, nP, patches);

@@ -338,3 +338,25 @@ def test_full_batch_properties(fe):
     Sh, hh, ph = host(S), host(harm), host(perc)
     for i in (0, 63, 511, 1023):
         assert np.array_equal(hh[i], ofe.median_time(Sh[i], 21)) and np.array_equal(ph[i], ofe.median_freq(Sh[i], 11))
+
+
+def test_long_clips_take_the_streaming_paths(fe):
+    """Whole files, not one-second clips: 10 s (T = 998: frame-tiled medians, slab feature kernel, streaming
+    clip / standardise / patch kernels) against the oracle; 60 s for shape, finiteness and the patch contract."""
+    from sm_hpss_mtl_amd.synth import synth_clips
+    y = synth_clips(2, seed=21, n_samples=160000)
+    res = fe.run(torch.from_numpy(y).cuda(), W=68, shift=34)
+    fv, patches = host(res["fv"]), host(res["patches"])
+    nP = len(ofe.patch_starts(998, 68, 34))
+    assert fv.shape == (2, 240, 998) and patches.shape == (2 * nP, 68, 240)
+    for i in range(2):
+        ref = ofe.featuregram(y[i], "LogMelHarmPercSpec")
+        assert np.max(np.abs(fv[i] - ref)) <= 2e-3  # dB
+        refp = ofe.tcn_input(ofe.feature_patches(ref, 68, 34))
+        assert np.max(np.abs(patches[i * nP:(i + 1) * nP] - refp)) <= 2e-3
+    y60 = synth_clips(1, seed=22, n_samples=960000)
+    r60 = fe.run(torch.from_numpy(y60).cuda(), W=68, shift=68)
+    torch.cuda.synchronize()
+    assert r60["fv"].shape == (1, 240, 5998) and r60["patches"].shape[0] == len(ofe.patch_starts(5998, 68, 68))
+    assert torch.isfinite(r60["fv"]).all() and torch.isfinite(r60["patches"]).all()
+    assert float(r60["fv"][0, :120].max() - r60["fv"][0, :120].min()) <= 80.0 + 1e-3  # top_db span of the H array
