@@ -360,3 +360,18 @@ def test_long_clips_take_the_streaming_paths(fe):
     assert r60["fv"].shape == (1, 240, 5998) and r60["patches"].shape[0] == len(ofe.patch_starts(5998, 68, 68))
     assert torch.isfinite(r60["fv"]).all() and torch.isfinite(r60["patches"]).all()
     assert float(r60["fv"][0, :120].max() - r60["fv"][0, :120].min()) <= 80.0 + 1e-3  # top_db span of the H array
+
+
+def test_odd_large_batch_end_to_end(fe):
+    """5001 clips (not a multiple of anything): every clip equals its replica computed in a batch of 8."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    from sm_hpss_mtl_amd.synth import synth_clips
+    base = synth_clips(8, seed=31)
+    B = 5001
+    idx = (np.arange(B) * 5) % 8
+    audio = torch.from_numpy(base[idx]).cuda()
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=3, seed=3)
+    out = m.forward_device(fe.run(audio, W=68, shift=68)["patches"])
+    ref = m.forward_device(fe.run(torch.from_numpy(base).cuda(), W=68, shift=68)["patches"])
+    torch.cuda.synchronize()
+    assert out.shape == (B, 7) and torch.equal(out, ref[torch.from_numpy(idx).cuda()])
