@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E spec peak (6.29 TB/s measured copy ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (= vector peak)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (only for --model-dtype bf16)
 # algorithmic bytes / flops per clip, SURVEY 8(d) (K=201 bins, T=98 frames, 240 features, W=68)
 K_BINS, T_FRAMES, FEAT, W_PATCH = 201, 98, 240, 68
 BYTES = {
@@ -71,6 +72,8 @@ def main():
     ap.add_argument("--l-harm", type=int, default=17)
     ap.add_argument("--l-perc", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = mixed-precision network (BASELINE config 5); NOT the parity path, never the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +132,8 @@ def main():
                                            p(feat_out["patches"]), p(feat_out["maxkeys"]), st))
         if record is not None:
             record[3].record()
-        model.forward_device(feat_out["patches"], out=logits, trunk=trunk)
+        model.forward_device(feat_out["patches"], out=logits, trunk=trunk if args.model_dtype == "f32" else None,
+                             dtype=args.model_dtype)
         if record is not None:
             record[4].record()
 
@@ -158,9 +162,10 @@ def main():
     for n in ("stft", "median", "features"):
         gbs = BYTES[n] * B / (ms[n] * 1e-3) / 1e9
         kernels[n] = {"ms": round(ms[n], 4), "bound": "hbm", "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    mfma_peak = MFMA_F32_PEAK_TFLOPS if args.model_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
     tf = FLOPS_MODEL * B / (ms["model"] * 1e-3) / 1e12
     kernels["model"] = {"ms": round(ms["model"], 4), "bound": "mfma", "achieved_TFLOPs": round(tf, 2),
-                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+                        "frac": round(tf / mfma_peak, 4)}
     # measured HBM traffic per launch from the committed rocprofv3 PMC passes (tools/gpu/collect_profiles.sh)
     pmc = {}
     try:
@@ -192,8 +197,9 @@ def main():
                                     "frac": round(pgbs / HBM_PEAK_GBS, 4), "in_value": False}
     dominant = max(names, key=lambda n: ms[n])
     if dominant == "model":
-        roof = {"kernel": "tcn_trunk_kernel+heads_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic(["model"]) if B == 1024 else None}
+        roof = {"kernel": "b3mtl_forward_kernel" if args.model_dtype == "f32" else "b3mtl_forward_bf16_kernel", "bound": "mfma",
+                "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
+                "traffic": traffic(["model"]) if (B == 1024 and args.model_dtype == "f32") else None}
     else:
         kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel", "features": "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
         roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -206,7 +212,7 @@ def main():
             "metric": "clips/sec HPSS+MTL-CNN fwd (1s@16kHz)", "value": round(clips_total / elapsed, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.model_dtype == "f32" else "f32 front end + bf16 network operands", "data": "synthetic",
             "config": {"workload": "%d x 1s@16kHz clips per GPU: STFT(400/160) -> HPSS %dx%d median + soft mask -> logmel(120) "
                                    "-> standardise -> patch W=68 -> B3_MTL(3-class) forward" % (B, args.l_harm, args.l_perc),
                        "clips_per_gpu": B, "l_harm": args.l_harm, "l_perc": args.l_perc, "patch": W_PATCH, "sharding": "per-clip, no data-path collective"},

@@ -199,6 +199,10 @@ int smh_model_out_dim(const smh_model *m);
 int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
 
 /* download the (device-resident, possibly trained) weights in canonical order */
+/* Same forward with bf16 matrix-core operands and f32 accumulation / residual stream / normalisation (BASELINE config
+ * 5, "mixed bf16 CNN + fp32 HPSS").  Weights are rounded once per weight version, activations right before each
+ * product.  NOT the parity path: outputs differ from smh_model_forward_f32 by up to a few 1e-2 (tests state it).   */
+int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream);
 int smh_model_get_weights(const smh_model *m, float *h_flat, size_t n, void *stream);
 
 /* ---- a13: Conv2D MTL baselines, inference forward (lib/proposed_architectures.py:425-511 Doukhan, :516-588

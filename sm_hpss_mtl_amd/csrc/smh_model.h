@@ -46,6 +46,9 @@ struct smh_model {
     float *d_hp = nullptr;    // per-head BN / out params
     int *d_map = nullptr;     // gather map: packed[i] = map[i] ? flat[map[i]-1] : 0 for [W0 | Wb | WhA | hp]
     size_t nW0, nWb, nWhA, nhp;
+    // bf16 operand cache of smh_model_forward_bf16 (smh_tcn_bf16.hip): rebuilt when `version` moves
+    void *d_bf16 = nullptr;
+    unsigned long long version = 1, bf16_version = 0;
 };
 
 namespace smh_tcn {

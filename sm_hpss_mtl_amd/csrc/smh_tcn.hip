@@ -454,6 +454,7 @@ Offsets offsets(const smh_model *m) {
 }
 
 int repack(smh_model *m, hipStream_t st) {
+    m->version++;  // every change of the master weights passes through here
     const size_t n = m->nW0 + m->nWb + m->nWhA + m->nhp;
     // the four operand buffers are one allocation: d_W0 is its base
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->d_flat, m->d_map, m->d_W0, n);
@@ -584,6 +585,7 @@ extern "C" void smh_model_destroy(smh_model *m) {
     (void)hipFree(m->d_flat);
     (void)hipFree(m->d_W0);  // base of the four operand buffers
     (void)hipFree(m->d_map);
+    (void)hipFree(m->d_bf16);
     delete m;
 }
 

@@ -170,8 +170,10 @@ class B3MTL(TrainingMixin):
                        "smh_model_set_weights")
             self._dirty = False
 
-    def forward_device(self, x, out=None, trunk=None):
-        """x: float32 CUDA tensor (N, W, n_feat) -> (N, out_dim) tensor [S|M|(N)|R|3C] on the device."""
+    def forward_device(self, x, out=None, trunk=None, dtype="f32"):
+        """x: float32 CUDA tensor (N, W, n_feat) -> (N, out_dim) tensor [S|M|(N)|R|3C] on the device.
+        dtype="bf16" selects the mixed-precision kernel (bf16 matrix-core operands, f32 everything else): faster,
+        not the parity path."""
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
             raise TypeError("forward_device expects a float32 CUDA tensor")
         x = x.contiguous()
@@ -181,6 +183,15 @@ class B3MTL(TrainingMixin):
         N = x.shape[0]
         if out is None:
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x.device)
+        if dtype == "bf16":
+            if trunk is not None:
+                raise ValueError("the trunk tap is only available on the f32 path")
+            _lib.check(self.lib.smh_model_forward_bf16(
+                self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_bf16")
+            return out
+        if dtype != "f32":
+            raise ValueError("dtype must be 'f32' or 'bf16'")
         _lib.check(self.lib.smh_model_forward_f32(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),
@@ -196,11 +207,11 @@ class B3MTL(TrainingMixin):
         res.append(out[:, col:col + self.n_classes])
         return res
 
-    def predict(self, x, batch_size=None, verbose=0):
+    def predict(self, x, batch_size=None, verbose=0, dtype="f32"):
         """model.predict(x=batchData) -> [S, M, (N,) R, 3C] numpy arrays (Proposed_Work_Results.py:520,586)."""
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
         elif x.dtype != torch.float32:
             x = x.float()
-        out = self.forward_device(x.cuda())
+        out = self.forward_device(x.cuda(), dtype=dtype)
         return [o.cpu().numpy() for o in self.split_outputs(out)]
