@@ -266,17 +266,31 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
             const bool live = j < g_here;
             const float *xg = xin + (size_t)(live ? j : 0) * T * SX + q;
-#pragma unroll 8
-            for (int s4 = s_lo; s4 < s_hi; ++s4) {
-                const f32x4 wv = wa[(size_t)s4 * 64];
-                // k = 16*s4 + 4*e + q  ->  t = s4 / 2, c = 16*(s4 & 1) + 4*e + q
-                const float *xr = xg + (size_t)(s4 >> 1) * SX + 16 * (s4 & 1);
-                float b0 = xr[0], b1 = xr[4], b2 = xr[8], b3 = xr[12];
-                if (!live) b0 = b1 = b2 = b3 = 0.f;
-                accA = mfma4(wv[0], b0, accA);
-                accB = mfma4(wv[1], b1, accB);
-                accA = mfma4(wv[2], b2, accA);
-                accB = mfma4(wv[3], b3, accB);
+            // The weights stream from L2 (one 16-byte load per lane and step): kHB loads are issued before the
+            // products of the previous group run, so a full group is always in flight (this loop was latency-bound).
+            constexpr int kHB = 16;
+            f32x4 wcur[kHB], wnxt[kHB];
+#pragma unroll
+            for (int e = 0; e < kHB; ++e) wcur[e] = wa[(size_t)min(s_lo + e, s_hi - 1) * 64];
+            for (int s0 = s_lo; s0 < s_hi; s0 += kHB) {
+#pragma unroll
+                for (int e = 0; e < kHB; ++e) wnxt[e] = wa[(size_t)min(s0 + kHB + e, s_hi - 1) * 64];
+#pragma unroll
+                for (int e = 0; e < kHB; ++e) {
+                    const int s4 = s0 + e;
+                    if (s4 < s_hi) {
+                        // k = 16*s4 + 4*e + q  ->  t = s4 / 2, c = 16*(s4 & 1) + 4*e + q
+                        const float *xr = xg + (size_t)(s4 >> 1) * SX + 16 * (s4 & 1);
+                        float b0 = xr[0], b1 = xr[4], b2 = xr[8], b3 = xr[12];
+                        if (!live) b0 = b1 = b2 = b3 = 0.f;
+                        accA = mfma4(wcur[e][0], b0, accA);
+                        accB = mfma4(wcur[e][1], b1, accB);
+                        accA = mfma4(wcur[e][2], b2, accA);
+                        accB = mfma4(wcur[e][3], b3, accB);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < kHB; ++e) wcur[e] = wnxt[e];
             }
             accA += accB;
 #pragma unroll
