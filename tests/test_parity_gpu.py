@@ -122,6 +122,29 @@ def test_median_ragged_shapes_ties_and_tiny_axes(fe, K, T):
             assert np.array_equal(pf[i], ofe.median_freq(S[i], w)), ("freq", K, T, w)
 
 
+def test_median_randomised_shapes_and_windows(fe):
+    """40 seeded random (K, T, l_harm, l_perc, B) draws: pairs and single filters, block-split / persistent / delete-
+    insert / rank-counting kernels, one- and multi-tile clips, batches on both sides of the persistent threshold."""
+    rng = np.random.default_rng(2024)
+    wins = [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 31, 41, 63]
+    for trial in range(40):
+        K, T = int(rng.integers(2, 300)), int(rng.integers(2, 420))
+        lh, lp = int(rng.choice(wins)), int(rng.choice(wins))
+        if trial % 5 == 0:
+            lh, lp = [(21, 11), (17, 17), (11, 21), (21, 21), (11, 11)][(trial // 5) % 5]  # fused pair kernels
+        B = int(rng.choice([1, 2, 3, 600])) if K * T < 12000 else int(rng.choice([1, 2]))
+        S = np.abs(rng.standard_normal((min(B, 3), K, T))).astype(np.float32)
+        if trial % 3 == 0:
+            S = np.round(S * 3) / 3  # ties
+        Sd = dev(S[np.arange(B) % S.shape[0]])
+        harm, perc = fe.hpss_median(Sd, lh, lp)
+        harm, perc = host(harm), host(perc)
+        for i in {0, B // 2, B - 1}:
+            ref = S[i % S.shape[0]]
+            assert np.array_equal(harm[i], ofe.median_time(ref, lh)), ("harm", trial, K, T, lh, lp, B, i)
+            assert np.array_equal(perc[i], ofe.median_freq(ref, lp)), ("perc", trial, K, T, lh, lp, B, i)
+
+
 def test_median_rejects_bad_windows(fe):
     S = dev(np.ones((1, 20, 20), np.float32))
     with pytest.raises(ValueError):
