@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--l-harm", type=int, default=17)
     ap.add_argument("--l-perc", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse-l0", action="store_true",
+                    help="write standardised patches and let the network read them (the reference's call structure) instead "
+                         "of computing the network's first 1x1 convolution inside the feature kernel")
     ap.add_argument("--model-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = mixed-precision network (BASELINE config 5); NOT the parity path, never the default")
     args = ap.parse_args()
@@ -115,6 +118,10 @@ def main():
     lib, h = fe.lib, fe._h
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
+    fuse_l0 = (not args.no_fuse_l0) and args.model_dtype == "f32"
+    model._sync_weights()
+    w0_ptr = C.c_void_p(lib.smh_model_w0_ptr(model._h))
+    x0p = torch.empty((B, 2, W_PATCH, 32), device=dev)
     names = ["stft", "median", "features", "model"]
     ev = None
 
@@ -128,12 +135,19 @@ def main():
         lay = _lib.check(lib.smh_hpss_median_ex_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), 1, st))
         if record is not None:
             record[2].record()
-        _lib.check(lib.smh_features_ex_f32(h, p(S), p(harm), p(perc), lay, B, T, W_PATCH, W_PATCH, p(feat_out["fv"]),
-                                           p(feat_out["patches"]), p(feat_out["maxkeys"]), st))
+        if fuse_l0:
+            _lib.check(lib.smh_features_l0_f32(h, p(S), p(harm), p(perc), lay, B, T, W_PATCH, W_PATCH, p(feat_out["fv"]), None,
+                                               w0_ptr, p(x0p), p(feat_out["maxkeys"]), st))
+        else:
+            _lib.check(lib.smh_features_ex_f32(h, p(S), p(harm), p(perc), lay, B, T, W_PATCH, W_PATCH, p(feat_out["fv"]),
+                                               p(feat_out["patches"]), p(feat_out["maxkeys"]), st))
         if record is not None:
             record[3].record()
-        model.forward_device(feat_out["patches"], out=logits, trunk=trunk if args.model_dtype == "f32" else None,
-                             dtype=args.model_dtype)
+        if fuse_l0:
+            model.forward_from_x0(x0p, out=logits, trunk=trunk)
+        else:
+            model.forward_device(feat_out["patches"], out=logits, trunk=trunk if args.model_dtype == "f32" else None,
+                                 dtype=args.model_dtype)
         if record is not None:
             record[4].record()
 
@@ -160,10 +174,14 @@ def main():
     ms = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
     kernels = {}
     for n in ("stft", "median", "features"):
-        gbs = BYTES[n] * B / (ms[n] * 1e-3) / 1e9
+        nbytes = BYTES[n]
+        if n == "features" and fuse_l0:  # the two layer-0 partials (2 x 68 x 32 f32) leave instead of the patches
+            nbytes += 2 * W_PATCH * 32 * 4 - W_PATCH * FEAT * 4
+        gbs = nbytes * B / (ms[n] * 1e-3) / 1e9
         kernels[n] = {"ms": round(ms[n], 4), "bound": "hbm", "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     mfma_peak = MFMA_F32_PEAK_TFLOPS if args.model_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
-    tf = FLOPS_MODEL * B / (ms["model"] * 1e-3) / 1e12
+    flops_model = FLOPS_MODEL - (2.0 * W_PATCH * FEAT * 32 if fuse_l0 else 0.0)  # layer 0 runs in the feature kernel when fused
+    tf = flops_model * B / (ms["model"] * 1e-3) / 1e12
     kernels["model"] = {"ms": round(ms["model"], 4), "bound": "mfma", "achieved_TFLOPs": round(tf, 2),
                         "frac": round(tf / mfma_peak, 4)}
     # measured HBM traffic per launch from the committed rocprofv3 PMC passes (tools/gpu/collect_profiles.sh)
@@ -215,7 +233,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.model_dtype == "f32" else "f32 front end + bf16 network operands", "data": "synthetic",
             "config": {"workload": "%d x 1s@16kHz clips per GPU: STFT(400/160) -> HPSS %dx%d median + soft mask -> logmel(120) "
                                    "-> standardise -> patch W=68 -> B3_MTL(3-class) forward" % (B, args.l_harm, args.l_perc),
-                       "clips_per_gpu": B, "l_harm": args.l_harm, "l_perc": args.l_perc, "patch": W_PATCH, "sharding": "per-clip, no data-path collective"},
+                       "clips_per_gpu": B, "layer0_fused_into_features": bool(fuse_l0), "l_harm": args.l_harm, "l_perc": args.l_perc, "patch": W_PATCH, "sharding": "per-clip, no data-path collective"},
             "roofline": roof, "kernels": kernels,
             "hbm_roofline_pct_median_kernel": round(100 * kernels["median"]["frac"], 2),
         }

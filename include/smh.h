@@ -199,6 +199,16 @@ int smh_model_out_dim(const smh_model *m);
 int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
 
 /* download the (device-resident, possibly trained) weights in canonical order */
+/* Fusion of the network's first layer into the feature stage (bench fast path; same logits within f32 tolerance):
+ * smh_features_l0_f32 = smh_features_ex_f32 that also emits, per clip half, its share of B3_MTL's initial Conv1D(32, 1)
+ * on the standardised patches, d_x0p (B*nP, 2, W, 32) float32, from the canonical kernel d_w0 = smh_model_w0_ptr(model)
+ * ((n_feat, 32), n_feat = 2 * feat_rows); d_patches may be null.  smh_model_forward_x0_f32 = smh_model_forward_f32
+ * that starts from those partials (adds them and the bias) instead of reading (N, W, n_feat) patches.              */
+const float *smh_model_w0_ptr(const smh_model *m);
+int smh_features_l0_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int harm_layout,
+                        int B, int T, int W, int shift, float *d_fv, float *d_patches, const float *d_w0, float *d_x0p,
+                        int32_t *d_maxkeys, void *stream);
+int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk, void *stream);
 /* Same forward with bf16 matrix-core operands and f32 accumulation / residual stream / normalisation (BASELINE config
  * 5, "mixed bf16 CNN + fp32 HPSS").  Weights are rounded once per weight version, activations right before each
  * product.  NOT the parity path: outputs differ from smh_model_forward_f32 by up to a few 1e-2 (tests state it).   */

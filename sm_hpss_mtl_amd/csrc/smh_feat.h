@@ -20,8 +20,9 @@ MelTable mel_table(const smh_ctx *c);
 int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,
                    float *fv, int *maxkeys, hipStream_t st);
 // top_db clip (in place) + StandardScaler + time-major patches
+// w0 / x0p non-null: also emit this half's share of the network's first Conv1D (see smh_features_l0_f32)
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
-                     float *patches, hipStream_t st);
+                     float *patches, hipStream_t st, const float *w0 = nullptr, float *x0p = nullptr);
 
 }  // namespace smh_feat
 

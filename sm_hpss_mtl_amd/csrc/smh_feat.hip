@@ -422,9 +422,10 @@ hp_feat_walk_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const 
 // ---------------------------------------------------------------------------------------------------
 constexpr int kPatchThreads = 1024;
 
+template <bool L0>
 __global__ void __launch_bounds__(kPatchThreads)
 std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ maxkeys, int rows, int T, int Ttiled, int W,
-                 int shift, int nP, float *__restrict__ patches) {
+                 int shift, int nP, float *__restrict__ patches, const float *__restrict__ w0, float *__restrict__ x0p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int b = blockIdx.y, half = blockIdx.x;
     const int ld = T | 1;
@@ -454,7 +455,7 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
         }
     }
     __syncthreads();
-    if (!patches) return;
+    if (!patches && !(L0 && x0p)) return;
     // StandardScaler statistics: ONE THREAD PER ROW (rows are short; a wave-wide f64 reduction per row
     // costs ~20x more instructions).  LDS reads are conflict-free: consecutive rows, odd row stride.
     float *s_mean = tile + (size_t)rows * ld, *s_inv = s_mean + rows;
@@ -482,6 +483,46 @@ std_patch_kernel(int log_db, float *__restrict__ fv, const int *__restrict__ max
     __syncthreads();
     const float *s_lo = s_mean + 2 * rows;
     const int F = 2 * rows;
+    if constexpr (L0) {
+        // Layer 0 of B3_MTL fused in (smh_features_l0_f32): this half's share of Conv1D(32, 1) on the standardised
+        // patch, D[channel][frame] = sum_r W0[half*rows + r][channel] * xstd[r][frame], exact-f32 MFMA straight from
+        // the LDS tile.  One (patch, 16-frame tile, channel half) per wave; the two halves of a clip write separate
+        // partial images (B*nP, 2, W, 32) that the network kernel adds (no atomics, no zero fill).  A separate
+        // instantiation: the plain kernel keeps its register count.
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const int q = lane >> 4, j = lane & 15;
+        const int ut = (W + 15) >> 4;
+        constexpr int kG = 8;  // weight loads in flight per group (8 measured best of 8 / 15 / 32: registers cost occupancy)
+        for (int task = wave; task < nP * ut * 2; task += nw) {
+            const int mt = task & 1, pu = task >> 1;
+            const int p = pu / ut, u = pu - p * ut;
+            int s = p * shift;
+            const int e = min(s + W, Ttiled);
+            if (e - s < W) s = e - W;
+            const int jt = 16 * u + j;                   // frame inside the patch
+            int tt = s + min(jt, W - 1);
+            tt -= (tt / T) * T;
+            const float *wr = w0 + ((size_t)half * rows + q) * 32 + 16 * mt + j;  // W0[f = half*rows + 4 st + q][c]
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+            const int nst = rows / 4;
+            for (int s0 = 0; s0 < nst; s0 += kG) {
+                float wa[kG];
+#pragma unroll
+                for (int g = 0; g < kG; ++g) wa[g] = wr[(size_t)(4 * min(s0 + g, nst - 1)) * 32];
+#pragma unroll
+                for (int g = 0; g < kG; ++g) {
+                    if (s0 + g < nst) {
+                        const int r = 4 * (s0 + g) + q;
+                        const float c = (float)((double)tile[r * ld + tt] - ((double)s_mean[r] + (double)s_lo[r]));
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], c * s_inv[r], c0, 0, 0, 0);
+                    }
+                }
+            }
+            if (jt < W)
+                *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 16 * mt + 4 * q) = c0;
+        }
+    }
+    if (!patches) return;
     for (int p = 0; p < nP; ++p) {
         int s = p * shift;
         const int e = min(s + W, Ttiled);
@@ -564,9 +605,12 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
 }
 
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
-                     float *patches, hipStream_t st) {
+                     float *patches, hipStream_t st, const float *w0, float *x0p) {
     const int rows = c->feat_rows;
     const size_t lds = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows);
+    if (x0p && (lds > 150 * 1024 || rows % 4 != 0 || rows > 128))
+        return smh::set_error(SMH_E_INVALID, "smh_features_l0_f32: needs a featuregram half that fits one LDS tile "
+                              "(T=%d) and a row count divisible by 4, at most 128 (rows=%d)", T, rows);
     if (lds > 150 * 1024) {
         // long clips: the same three steps as separate streaming kernels over a stream-ordered scratch copy
         if (B > 32767) return smh::set_error(SMH_E_INVALID, "B=%d too large for the long-clip path; split the batch", B);
@@ -593,9 +637,15 @@ int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int
         SMH_CHECK_HIP(hipFreeAsync(tmp, st));
         return rc;
     }
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(std_patch_kernel, dim3(2, B), dim3(kPatchThreads), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
-                       smh_tiled_frames(T, W), W, shift, nP, patches);
+    if (x0p) {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(std_patch_kernel<true>, dim3(2, B), dim3(kPatchThreads), lds, st, c->cfg.log_db, fv, maxkeys, rows,
+                           T, smh_tiled_frames(T, W), W, shift, nP, patches, w0, x0p);
+        return smh::launch_status("std_patch_kernel<l0>");
+    }
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)std_patch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(std_patch_kernel<false>, dim3(2, B), dim3(kPatchThreads), lds, st, c->cfg.log_db, fv, maxkeys, rows, T,
+                       smh_tiled_frames(T, W), W, shift, nP, patches, w0, x0p);
     return smh::launch_status("std_patch_kernel");
 }
 

@@ -32,6 +32,23 @@ extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const f
     return nP;
 }
 
+extern "C" int smh_features_l0_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc,
+                                   int harm_layout, int B, int T, int W, int shift, float *d_fv, float *d_patches,
+                                   const float *d_w0, float *d_x0p, int32_t *d_maxkeys, void *stream) {
+    SMH_REQUIRE(ctx && d_S && d_harm && d_perc && d_fv && d_maxkeys && d_w0 && d_x0p, "smh_features_l0_f32: null argument");
+    SMH_REQUIRE(B >= 0 && B <= 65535 && T >= 1, "smh_features_l0_f32: bad shape B=%d T=%d", B, T);
+    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_features_l0_f32: harm_layout must be 0 or 1");
+    SMH_REQUIRE(W >= 1 && shift >= 1, "smh_features_l0_f32: bad patch geometry W=%d shift=%d", W, shift);
+    const int nP = smh_num_patches(smh_tiled_frames(T, W), W, shift);
+    if (B == 0 || nP <= 0) return nP;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = smh_feat::launch_hp_feat(ctx, d_S, d_harm, d_perc, harm_layout, B, T, d_fv, (int *)d_maxkeys, st);
+    if (rc) return rc;
+    rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)d_maxkeys, B, T, W, shift, nP, d_patches, st, d_w0, d_x0p);
+    if (rc) return rc;
+    return nP;
+}
+
 extern "C" int smh_features_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, int B,
                                 int T, int W, int shift, float *d_fv, float *d_patches, int32_t *d_maxkeys,
                                 void *stream) {

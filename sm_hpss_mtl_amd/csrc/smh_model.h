@@ -21,6 +21,7 @@ constexpr int kBlockFloats = 24 * 2 * 64 + 8 * 2 * 64 + 32 + 32;
 struct TcnArgs {
     int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
     int D, NH, n_mt, n_classes, n_heads, out_dim, skip_heads;
+    int from_x0;  // X holds the two per-half partials of layer 0, (N, 2, T, 32) (smh_features_l0_f32), instead of patches
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];
 };
@@ -63,5 +64,5 @@ Offsets offsets(const smh_model *m);
 void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
 int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
-                   hipStream_t st);
+                   hipStream_t st, int from_x0 = 0);
 }  // namespace smh_tcn

@@ -152,7 +152,17 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         const float *bias0 = W0 + (size_t)nW0;
         const f32x4 bl = *reinterpret_cast<const f32x4 *>(bias0 + 4 * q);
         const f32x4 bh = *reinterpret_cast<const f32x4 *>(bias0 + 16 + 4 * q);
-        if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kMaxU * nw) {
+        if (a.from_x0) {
+            // layer 0 was computed by the feature kernel: sum its two per-half partials, add the bias
+            for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
+                const int R = i >> 3, c4 = (i & 7) * 4;
+                const int g = R / T, t = R - g * T;
+                const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + t) * C + c4);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(p0) + *reinterpret_cast<const f32x4 *>(p0 + (size_t)T * C) +
+                          *reinterpret_cast<const f32x4 *>(bias0 + c4);
+                *reinterpret_cast<f32x4 *>(xa + (size_t)R * SX + c4) = v;
+            }
+        } else if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kMaxU * nw) {
             f32x4 xr[kMaxU][kFQ4];
 #pragma unroll
             for (int i = 0; i < kMaxU; ++i) {
@@ -481,6 +491,7 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     a.N = N, a.T = T, a.F = m->cfg.n_feat, a.FQ = m->FQ, a.n_blocks = m->n_blocks, a.n_dil = m->cfg.n_dilations;
     a.vec_ok = (a.F % 4 == 0) && (a.FQ % 4 == 0) && (a.FQ * 4 == a.F);
     a.skip_heads = 0;
+    a.from_x0 = 0;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
     for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
@@ -506,10 +517,11 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
 }
 
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
-                   hipStream_t st) {
+                   hipStream_t st, int from_x0) {
     TcnArgs a;
     size_t lds;
     fill_args(m, N, &a, &lds);
+    a.from_x0 = from_x0;
     if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
     a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
@@ -624,6 +636,18 @@ extern "C" int smh_model_get_weights(const smh_model *m, float *h, size_t n, voi
     SMH_CHECK_HIP(hipMemcpyAsync(h, m->d_flat, n * sizeof(float), hipMemcpyDeviceToHost, st));
     SMH_CHECK_HIP(hipStreamSynchronize(st));
     return SMH_OK;
+}
+
+extern "C" const float *smh_model_w0_ptr(const smh_model *m) {
+    return m ? m->d_flat + smh_tcn::offsets(m).w0_k : nullptr;
+}
+
+extern "C" int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk,
+                                        void *stream) {
+    SMH_REQUIRE(m && d_x0p && d_out, "smh_model_forward_x0_f32: null argument");
+    SMH_REQUIRE(N >= 0, "smh_model_forward_x0_f32: N=%d", N);
+    if (N == 0) return SMH_OK;
+    return smh_tcn::launch_forward(m, d_x0p, N, d_out, d_trunk, nullptr, (hipStream_t)stream, 1);
 }
 
 extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk,

@@ -202,6 +202,30 @@ class Frontend:
         assert got == nP
         return {"fv": fv, "patches": patches, "n_patches": nP, "maxkeys": keys}
 
+    def features_l0(self, S, harm, perc, harm_layout, W, shift, model, out=None, patches=False):
+        """`features` fused with the first layer of `model` (B3MTL): returns dict(fv, x0p (B*nP, 2, W, 32)[, patches]).
+        Feed x0p to `model.forward_from_x0`.  Same logits as features -> forward_device within f32 tolerance."""
+        S, harm, perc = _f32c(S, "S"), _f32c(harm, "harm"), _f32c(perc, "perc")
+        B, K, T = S.shape
+        if model.n_feat != 2 * self.rows or model.patch_size != W:
+            raise ValueError("model expects (W=%d, n_feat=%d), the front end produces (W=%d, n_feat=%d)"
+                             % (model.patch_size, model.n_feat, W, 2 * self.rows))
+        model._sync_weights()
+        out = {} if out is None else out
+        nP = self.num_patches(T, W, shift)
+        dev = S.device
+        fv = out.get("fv") if out.get("fv") is not None else torch.empty((B, 2 * self.rows, T), dtype=torch.float32, device=dev)
+        x0p = out.get("x0p") if out.get("x0p") is not None else torch.empty((B * nP, 2, W, 32), dtype=torch.float32, device=dev)
+        pt = None
+        if patches:
+            pt = out.get("patches") if out.get("patches") is not None else torch.empty((B * nP, W, 2 * self.rows), dtype=torch.float32, device=dev)
+        keys = out.get("maxkeys") if out.get("maxkeys") is not None else torch.empty(2 * max(B, 1), dtype=torch.int32, device=dev)
+        got = _lib.check(self.lib.smh_features_l0_f32(
+            self._h, _ptr(S), _ptr(harm), _ptr(perc), int(harm_layout), B, T, W, shift, _ptr(fv), _ptr(pt),
+            C.c_void_p(self.lib.smh_model_w0_ptr(model._h)), _ptr(x0p), _ptr(keys), _stream()), "smh_features_l0_f32")
+        assert got == nP
+        return {"fv": fv, "x0p": x0p, "patches": pt, "n_patches": nP, "maxkeys": keys}
+
     # ---- fused fast path ----
     def run(self, audio, W=None, shift=None, taps=False, out=None):
         """audio (B, n_samples) -> dict(fv=(B, 2*rows, T)[, patches=(B*nP, W, 2*rows)][, S, harm, perc]).

@@ -198,6 +198,23 @@ class B3MTL(TrainingMixin):
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_f32")
         return out
 
+    def forward_from_x0(self, x0p, out=None, trunk=None):
+        """Forward that starts from the per-half layer-0 partials (N, 2, W, 32) written by `Frontend.features_l0`."""
+        if not (isinstance(x0p, torch.Tensor) and x0p.is_cuda and x0p.dtype == torch.float32):
+            raise TypeError("forward_from_x0 expects a float32 CUDA tensor")
+        x0p = x0p.contiguous()
+        if x0p.dim() != 4 or tuple(x0p.shape[1:]) != (2, self.patch_size, 32):
+            raise ValueError("expected (N, 2, %d, 32), got %s" % (self.patch_size, tuple(x0p.shape)))
+        self._sync_weights()
+        N = x0p.shape[0]
+        if out is None:
+            out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x0p.device)
+        _lib.check(self.lib.smh_model_forward_x0_f32(
+            self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()),
+            None if trunk is None else C.c_void_p(trunk.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_f32")
+        return out
+
     def split_outputs(self, out):
         """(N, out_dim) -> list in Keras output order [S, M, (N,) R, 3C]."""
         res, col = [], 0

@@ -398,3 +398,24 @@ def test_odd_large_batch_end_to_end(fe):
     ref = m.forward_device(fe.run(torch.from_numpy(base).cuda(), W=68, shift=68)["patches"])
     torch.cuda.synchronize()
     assert out.shape == (B, 7) and torch.equal(out, ref[torch.from_numpy(idx).cuda()])
+
+
+@pytest.mark.parametrize("W,shift,ncls", [(68, 68, 3), (68, 34, 5), (99, 34, 3)])
+def test_layer0_fused_into_features_matches_the_two_step_path(fe, clips4, W, shift, ncls):
+    """smh_features_l0_f32 + smh_model_forward_x0_f32 (the bench fast path) against features -> patches -> forward and
+    against the oracle; W = 99 exercises tile-if-short (98 frames)."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w = b3_mtl.init_weights(seed=4, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls, seed=0)
+    m.set_weights_dict(w)
+    S = fe.stft_mag(dev(clips4))
+    harm, perc = fe.hpss_median(S)
+    two = fe.features(S, harm, perc, W=W, shift=shift)
+    ref = m.forward_device(two["patches"])
+    fused = fe.features_l0(S, harm, perc, 0, W, shift, m, patches=True)
+    got = m.forward_from_x0(fused["x0p"])
+    torch.cuda.synchronize()
+    assert torch.equal(fused["fv"], two["fv"]) and torch.equal(fused["patches"], two["patches"])
+    assert float((got - ref).abs().max()) <= 2e-5
+    oracle = np.concatenate(b3_mtl.forward(host(two["patches"]), w, ncls), axis=1)
+    assert np.max(np.abs(host(got) - oracle)) <= 1e-4
