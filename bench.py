@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-fuse-l0", action="store_true",
                     help="write standardised patches and let the network read them (the reference's call structure) instead "
                          "of computing the network's first 1x1 convolution inside the feature kernel")
+    ap.add_argument("--two-kernel-features", action="store_true",
+                    help="time-major harm + hp_feat_walk / std_patch kernels instead of the single feature kernel")
     ap.add_argument("--model-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = mixed-precision network (BASELINE config 5); NOT the parity path, never the default")
     args = ap.parse_args()
@@ -108,7 +110,8 @@ def main():
     T = fe.num_frames(audio.shape[1])
     dev = audio.device
     S = torch.empty((B, fe.K, T), device=dev)
-    harm, perc = torch.empty_like(S), torch.empty_like(S)
+    perc = torch.empty_like(S)
+    harm = torch.empty((B, fe.lib.smh_harm_buffer_floats(fe.K, T)), device=dev)  # room for every harm layout
     feat_out = {"fv": torch.empty((B, FEAT, T), device=dev), "patches": torch.empty((B, W_PATCH, FEAT), device=dev),
                 "maxkeys": torch.empty(2 * B, dtype=torch.int32, device=dev)}
     logits = torch.empty((B, model.out_dim), device=dev)
@@ -122,6 +125,8 @@ def main():
     model._sync_weights()
     w0_ptr = C.c_void_p(lib.smh_model_w0_ptr(model._h))
     x0p = torch.empty((B, 2, W_PATCH, 32), device=dev)
+    # harmonic median layout: 16-frame blocks when the single-kernel feature path takes the clip, else time-major
+    want_lay = 2 if (lib.smh_features_blocked_ok(h, T, 1 if fuse_l0 else 0) and not args.two_kernel_features) else 1
     names = ["stft", "median", "features", "model"]
     ev = None
 
@@ -132,7 +137,7 @@ def main():
         _lib.check(lib.smh_stft_mag_f32(h, p(audio), B, audio.shape[1], p(S), st))
         if record is not None:
             record[1].record()
-        lay = _lib.check(lib.smh_hpss_median_ex_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), 1, st))
+        lay = _lib.check(lib.smh_hpss_median_ex_f32(h, p(S), B, fe.K, T, args.l_harm, args.l_perc, p(harm), p(perc), want_lay, st))
         if record is not None:
             record[2].record()
         if fuse_l0:
@@ -177,6 +182,8 @@ def main():
         nbytes = BYTES[n]
         if n == "features" and fuse_l0:  # the two layer-0 partials (2 x 68 x 32 f32) leave instead of the patches
             nbytes += 2 * W_PATCH * 32 * 4 - W_PATCH * FEAT * 4
+        if n == "features" and want_lay == 2:  # single kernel: the featuregram is written once and never re-read
+            nbytes -= FEAT * T_FRAMES * 4
         gbs = nbytes * B / (ms[n] * 1e-3) / 1e9
         kernels[n] = {"ms": round(ms[n], 4), "bound": "hbm", "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     mfma_peak = MFMA_F32_PEAK_TFLOPS if args.model_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
@@ -197,7 +204,7 @@ def main():
     def traffic(keys):
         vals = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in keys]
         return None if any(v is None for v in vals) else float(sum(vals))
-    for n, keys in (("stft", ["stft"]), ("median", ["median"]), ("features", ["hp_feat", "std_patch"]), ("model", ["model"])):
+    for n, keys in (("stft", ["stft"]), ("median", ["median"]), ("features", ["features_clip"] if want_lay == 2 else ["hp_feat", "std_patch"]), ("model", ["model"])):
         kernels[n]["pmc_hbm_bytes_per_launch_at_B1024"] = traffic(keys)
     # the widened row in front of the path, measured separately: NOT part of `value`
     from sm_hpss_mtl_amd import silence as _sil
@@ -219,10 +226,10 @@ def main():
                 "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
                 "traffic": traffic(["model"]) if (B == 1024 and args.model_dtype == "f32") else None}
     else:
-        kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel", "features": "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
+        kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel", "features": "features_clip_kernel" if want_lay == 2 else "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
         roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dominant]["frac"],
-                "traffic": traffic({"stft": ["stft"], "median": ["median"], "features": ["hp_feat", "std_patch"]}[dominant]) if B == 1024 else None}
+                "traffic": traffic({"stft": ["stft"], "median": ["median"], "features": ["features_clip"] if want_lay == 2 else ["hp_feat", "std_patch"]}[dominant]) if B == 1024 else None}
 
     if rank == 0:
         clips_total = world * B * args.steps

@@ -52,6 +52,8 @@ SIGNATURES = {
     "smh_power_to_db_sq_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "smh_standardize_rows_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "smh_extract_patches_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),
+    "smh_harm_buffer_floats": (_sz, [_i, _i]),
+    "smh_features_blocked_ok": (_i, [_vp, _i, _i]),
     "smh_features_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
     "smh_features_ex_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
     "smh_frontend_workspace_bytes": (_sz, [_vp, _i, _i]),

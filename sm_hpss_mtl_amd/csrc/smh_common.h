@@ -61,9 +61,11 @@ struct smh_ctx {
     // of the (at most four) pending ones -- {w0, w1, w2, w3, n_emit, -, -, -} per bin, 32 bytes
     static constexpr int kMaxFeatSegs = 8;
     int feat_walk_ok;
-    int feat_nseg;
-    int feat_m0[kMaxFeatSegs], feat_m1[kMaxFeatSegs], feat_kbeg[kMaxFeatSegs], feat_kend[kMaxFeatSegs],
-        feat_off[kMaxFeatSegs];
+    // two segmentations of the same rows: [0] four segments (two-kernel path, 8 waves per clip),
+    // [1] eight segments (single-kernel path, 16 waves per clip)
+    int feat_nseg[2];
+    int feat_m0[2][kMaxFeatSegs], feat_m1[2][kMaxFeatSegs], feat_kbeg[2][kMaxFeatSegs], feat_kend[2][kMaxFeatSegs],
+        feat_off[2][kMaxFeatSegs];
     float *d_feat_plan;
     std::vector<float> h_mel_dense;  // (n_mels, K) host copy
 };

@@ -187,10 +187,8 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
     }
     c->mel_nnz = (int)mw.size();
     std::vector<float> plan;
-    {   // plan of the bin-walk feature kernel
+    {   // plans of the bin-walk feature kernels
         const int R = c->feat_rows;
-        int NS = 4;  // measured best of 3..8 at K = 201, T = 98 (tools/gpu/feat_segs.sh)
-        if (const char *ev = getenv("SMH_FEAT_SEGS")) NS = std::max(1, std::min(atoi(ev), (int)smh_ctx::kMaxFeatSegs));  // tuning
         std::vector<int> st(R), en(R);
         for (int i = 0; i < R; ++i) {
             st[i] = c->n_mels > 0 ? mstart[i] : i;
@@ -198,40 +196,45 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
         }
         auto weight = [&](int m, int k) { return c->n_mels > 0 ? mw[moff[m] + (k - st[m])] : 1.0f; };
         bool ok = true;
-        int bound[smh_ctx::kMaxFeatSegs + 1];
-        bound[0] = 0;
-        for (int sgm = 1; sgm < NS; ++sgm) {  // boundaries where the filter start crosses sgm/NS of the bins
-            int m = bound[sgm - 1];
-            while (m < R && st[m] < (long)c->K * sgm / NS) ++m;
-            bound[sgm] = m;
-        }
-        bound[NS] = R;
-        c->feat_nseg = 0;
-        for (int sgm = 0; sgm < NS; ++sgm) {
-            const int m0 = bound[sgm], m1 = bound[sgm + 1];
-            if (m0 >= m1) continue;
-            int kbeg = c->K, kend = 0;
-            for (int m = m0; m < m1; ++m)
-                if (en[m] > st[m]) kbeg = std::min(kbeg, st[m]), kend = std::max(kend, en[m]);
-            if (kend <= kbeg) kbeg = kend = 0;
-            const int q = c->feat_nseg++;
-            c->feat_m0[q] = m0, c->feat_m1[q] = m1, c->feat_kbeg[q] = kbeg, c->feat_kend[q] = kend;
-            c->feat_off[q] = (int)plan.size();
-            int mcur = m0;
-            for (int k = kbeg; k < kend; ++k) {
-                int nemit = 0;
-                while (mcur < m1 && k >= en[mcur]) ++mcur, ++nemit;
-                float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < 2; ++v) {
+            int NS = v == 0 ? 4 : 8;  // 4 measured best of 3..8 for the two-kernel path at K = 201, T = 98
+            if (const char *ev = getenv(v == 0 ? "SMH_FEAT_SEGS" : "SMH_FEAT_SEGS1"))
+                NS = std::max(1, std::min(atoi(ev), (int)smh_ctx::kMaxFeatSegs));  // tuning
+            int bound[smh_ctx::kMaxFeatSegs + 1];
+            bound[0] = 0;
+            for (int sgm = 1; sgm < NS; ++sgm) {  // boundaries where the filter start crosses sgm/NS of the bins
+                int m = bound[sgm - 1];
+                while (m < R && st[m] < (long)c->K * sgm / NS) ++m;
+                bound[sgm] = m;
+            }
+            bound[NS] = R;
+            c->feat_nseg[v] = 0;
+            for (int sgm = 0; sgm < NS; ++sgm) {
+                const int m0 = bound[sgm], m1 = bound[sgm + 1];
+                if (m0 >= m1) continue;
+                int kbeg = c->K, kend = 0;
                 for (int m = m0; m < m1; ++m)
-                    if (st[m] <= k && k < en[m]) {
-                        if (m < mcur || m > mcur + 3) ok = false;  // more than four pending filters, or out of order
-                        else w4[m - mcur] = weight(m, k);
-                    }
-                for (int e = 0; e < 4; ++e) plan.push_back(w4[e]);
-                float ne;
-                std::memcpy(&ne, &nemit, sizeof(float));
-                plan.push_back(ne);
-                plan.push_back(0.f), plan.push_back(0.f), plan.push_back(0.f);
+                    if (en[m] > st[m]) kbeg = std::min(kbeg, st[m]), kend = std::max(kend, en[m]);
+                if (kend <= kbeg) kbeg = kend = 0;
+                const int q = c->feat_nseg[v]++;
+                c->feat_m0[v][q] = m0, c->feat_m1[v][q] = m1, c->feat_kbeg[v][q] = kbeg, c->feat_kend[v][q] = kend;
+                c->feat_off[v][q] = (int)plan.size();
+                int mcur = m0;
+                for (int k = kbeg; k < kend; ++k) {
+                    int nemit = 0;
+                    while (mcur < m1 && k >= en[mcur]) ++mcur, ++nemit;
+                    float w4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int m = m0; m < m1; ++m)
+                        if (st[m] <= k && k < en[m]) {
+                            if (m < mcur || m > mcur + 3) ok = false;  // more than four pending filters, or out of order
+                            else w4[m - mcur] = weight(m, k);
+                        }
+                    for (int e = 0; e < 4; ++e) plan.push_back(w4[e]);
+                    float ne;
+                    std::memcpy(&ne, &nemit, sizeof(float));
+                    plan.push_back(ne);
+                    plan.push_back(0.f), plan.push_back(0.f), plan.push_back(0.f);
+                }
             }
         }
         c->feat_walk_ok = ok ? 1 : 0;

@@ -20,6 +20,10 @@ MelTable mel_table(const smh_ctx *c);
 int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,
                    float *fv, int *maxkeys, hipStream_t st);
 // top_db clip (in place) + StandardScaler + time-major patches
+// everything after the medians in one kernel per clip; harmb = harm in layout 2 (B, ceil(T/16), K, 16).
+// Returns 1 if it ran, 0 if the shape does not qualify (the caller must then not have asked for layout 2), < 0 on error
+int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, const float *perc, int B, int T, int W,
+                         int shift, int nP, float *fv, float *patches, const float *w0, float *x0p, hipStream_t st);
 // w0 / x0p non-null: also emit this half's share of the network's first Conv1D (see smh_features_l0_f32)
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
                      float *patches, hipStream_t st, const float *w0 = nullptr, float *x0p = nullptr);

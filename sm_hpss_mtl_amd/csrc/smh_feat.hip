@@ -550,6 +550,191 @@ __global__ void clip_fv_kernel(float *__restrict__ fv, const int *__restrict__ m
         g[i] = fmaxf(g[i], thr);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fused fast path as ONE kernel per clip (harm in the 16-frame blocked layout written by the block-split median
+// kernels, clips whose whole featuregram fits in LDS).  The bin walk of hp_feat_walk_kernel -- 8 row segments x 2
+// waves = 16 waves, every lane a frame -- emits the un-clipped dB rows into an LDS image of the featuregram; the
+// per-array maximum is then known inside the workgroup, so the top-dB clip, the StandardScaler statistics, the final
+// featuregram (its only trip to HBM), the standardised patches and / or the network's first layer (section 12 of
+// DESIGN.md) follow from LDS.  No harm tile: lane t reads harm[t/16][k][t%16], 64-byte runs per bin.
+// HBM traffic per clip: S + harm + perc in, featuregram + layer-0 partials out = 360 KB instead of 566 KB.
+// LDS: image [2*rows][T|1] + 3 floats per row + 32 ints  (98 frames, 240 rows: 98 KB, one workgroup per CU).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const float *__restrict__ harmb,
+                     const float *__restrict__ perc, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
+                     float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
+                     float *__restrict__ x0p) {
+    extern __shared__ __attribute__((aligned(16))) float img[];  // [R2][ld]
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int b = blockIdx.x;
+    const int ld = T | 1, R2 = 2 * rows;
+    float *s_mean = img + (size_t)R2 * ld;  // mean hi [R2], 1/scale [R2], mean lo [R2]
+    float *s_inv = s_mean + R2, *s_lo = s_mean + 2 * R2;
+    int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)R2);  // 32 ints
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const size_t cb = (size_t)b * K * T;
+    const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
+    float mxH = -FLT_MAX, mxP = -FLT_MAX;
+
+    const int nwt = (T + 63) >> 6;
+    for (int task = wave; task < fp.nseg * nwt; task += nw) {
+        const int seg = __builtin_amdgcn_readfirstlane(task / nwt);
+        const int tw = task - seg * nwt;
+        const int t = tw * 64 + lane;
+        const bool active = t < T;
+        const int tc = min(t, T - 1);
+        const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
+        int mcur = fp.m0[seg];
+        const float *plan = fp.plan + fp.off[seg];
+        float aH[4] = {0.f, 0.f, 0.f, 0.f}, aP[4] = {0.f, 0.f, 0.f, 0.f};
+        auto emit_first = [&]() {
+            float vH = aH[0], vP = aP[0];
+            if (log_db) {
+                vH = db_of_sq_fast(vH), vP = db_of_sq_fast(vP);
+                mxH = fmaxf(mxH, vH), mxP = fmaxf(mxP, vP);
+            }
+            if (active) {
+                img[mcur * ld + tc] = vH;
+                img[(rows + mcur) * ld + tc] = vP;
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) aH[e] = aH[e + 1], aP[e] = aP[e + 1];
+            aH[3] = aP[3] = 0.f;
+            ++mcur;
+        };
+        const float *Sb = S + cb + tc, *Pb = perc + cb + tc;
+        const float *Hb = hclip + (size_t)(tc >> 4) * K * 16 + (tc & 15);
+        for (int k0 = kbeg; k0 < kend; k0 += kWalkBatch) {
+            float sv[kWalkBatch], pv[kWalkBatch], hv[kWalkBatch];
+            float4 wq[kWalkBatch];
+            int ne[kWalkBatch];
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                const int kk = min(k0 + u, K - 1);
+                sv[u] = Sb[(size_t)kk * T];
+                pv[u] = Pb[(size_t)kk * T];
+                hv[u] = Hb[(size_t)kk * 16];
+                const int pi = min(k0 + u, kend - 1) - kbeg;
+                wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
+                ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                if (k0 + u >= kend) break;
+                for (int i = 0; i < ne[u]; ++i) emit_first();
+                float H, P;
+                hpss_masks_fast(sv[u], hv[u], pv[u], H, P);
+                aH[0] = fmaf(wq[u].x, H, aH[0]), aP[0] = fmaf(wq[u].x, P, aP[0]);
+                aH[1] = fmaf(wq[u].y, H, aH[1]), aP[1] = fmaf(wq[u].y, P, aP[1]);
+                aH[2] = fmaf(wq[u].z, H, aH[2]), aP[2] = fmaf(wq[u].z, P, aP[2]);
+                aH[3] = fmaf(wq[u].w, H, aH[3]), aP[3] = fmaf(wq[u].w, P, aP[3]);
+            }
+        }
+        while (mcur < m1) emit_first();
+    }
+    // per-array maximum -> top_db thresholds
+    float thrH = -FLT_MAX, thrP = -FLT_MAX;
+    {
+        int kH = ordered_key(mxH), kP = ordered_key(mxP);
+        for (int off = 32; off > 0; off >>= 1) {
+            kH = max(kH, __shfl_xor(kH, off));
+            kP = max(kP, __shfl_xor(kP, off));
+        }
+        if (lane == 0) smax[wave] = kH, smax[16 + wave] = kP;
+        __syncthreads();  // also: the image is complete
+        if (log_db) {
+            int a = smax[0], c = smax[16];
+            for (int q = 1; q < nw; ++q) a = max(a, smax[q]), c = max(c, smax[16 + q]);
+            thrH = key_to_float(a) - kTopDb, thrP = key_to_float(c) - kTopDb;
+        }
+    }
+    // clip in LDS, write the final featuregram (coalesced rows)
+    float *g = fv + (size_t)b * R2 * T;
+    for (int r = wave; r < R2; r += nw) {
+        const float thr = r < rows ? thrH : thrP;
+        for (int t = lane; t < T; t += 64) {
+            const float x = fmaxf(img[r * ld + t], thr);
+            img[r * ld + t] = x;
+            g[(size_t)r * T + t] = x;
+        }
+    }
+    __syncthreads();
+    if ((!patches && !x0p) || nP <= 0) return;
+    // StandardScaler statistics: one thread per row, f64 (see std_patch_kernel)
+    for (int r = threadIdx.x; r < R2; r += blockDim.x) {
+        const float *row = img + r * ld;
+        double sum = 0.0;
+        for (int t = 0; t < T; ++t) sum += (double)row[t];
+        const double mean = sum / (double)T;
+        double qv = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double dlt = (double)row[t] - mean;
+            qv += dlt * dlt;
+        }
+        const double var = qv / (double)T;
+        const double eps = 2.220446049250313e-16;
+        const double nm = (double)T * mean * eps;
+        const bool constant = var <= (double)T * eps * var + nm * nm;
+        double scale = sqrt(var);
+        if (constant || scale == 0.0) scale = 1.0;
+        s_mean[r] = (float)mean;
+        s_inv[r] = (float)(1.0 / scale);
+        s_lo[r] = (float)(mean - (double)(float)mean);
+    }
+    __syncthreads();
+    if (x0p) {  // the network's first layer, per clip half (std_patch_kernel<true> has the derivation)
+        const int q = lane >> 4, j = lane & 15;
+        const int ut = (W + 15) >> 4;
+        constexpr int kG = 8;
+        for (int task = wave; task < nP * ut * 4; task += nw) {
+            const int mt = task & 1, half = (task >> 1) & 1, pu = task >> 2;
+            const int p = pu / ut, u = pu - p * ut;
+            int s = p * shift;
+            const int e = min(s + W, Ttiled);
+            if (e - s < W) s = e - W;
+            const int jt = 16 * u + j;
+            int tt = s + min(jt, W - 1);
+            tt -= (tt / T) * T;
+            const float *wr = w0 + ((size_t)half * rows + q) * 32 + 16 * mt + j;
+            const float *tl = img + (size_t)half * rows * ld;
+            const float *mh = s_mean + half * rows, *ml = s_lo + half * rows, *iv = s_inv + half * rows;
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+            const int nst = rows / 4;
+            for (int s0 = 0; s0 < nst; s0 += kG) {
+                float wa[kG];
+#pragma unroll
+                for (int gI = 0; gI < kG; ++gI) wa[gI] = wr[(size_t)(4 * min(s0 + gI, nst - 1)) * 32];
+#pragma unroll
+                for (int gI = 0; gI < kG; ++gI) {
+                    if (s0 + gI < nst) {
+                        const int r = 4 * (s0 + gI) + q;
+                        const float c = (float)((double)tl[r * ld + tt] - ((double)mh[r] + (double)ml[r]));
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[gI], c * iv[r], c0, 0, 0, 0);
+                    }
+                }
+            }
+            if (jt < W)
+                *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 16 * mt + 4 * q) = c0;
+        }
+    }
+    if (!patches) return;
+    for (int p = 0; p < nP; ++p) {
+        int s0 = p * shift;
+        const int e = min(s0 + W, Ttiled);
+        if (e - s0 < W) s0 = e - W;
+        float *o = patches + ((size_t)b * nP + p) * W * R2;
+        for (int j = wave; j < W; j += nw) {  // one wave per frame: lanes over the 2*rows features (960-byte rows)
+            int tt = s0 + j;
+            tt -= (tt / T) * T;
+            for (int f = lane; f < R2; f += 64) {
+                const float c = (float)((double)img[f * ld + tt] - ((double)s_mean[f] + (double)s_lo[f]));
+                o[(size_t)j * R2 + f] = c * s_inv[f];
+            }
+        }
+    }
+}
+
 __global__ void fill_int_kernel(int *p, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -579,13 +764,13 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     }
     // bin-walk kernel: one workgroup per clip (SMH_FEAT_TAPS=1 forces the per-tap kernel below)
     const size_t lds_walk = sizeof(float) * (harm_tmajor ? (size_t)T * (K | 1) : 0) + 128;
-    const int walk_waves = c->feat_nseg * ((T + 63) / 64);
+    const int walk_waves = c->feat_nseg[0] * ((T + 63) / 64);
     if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !getenv("SMH_FEAT_TAPS")) {
         FeatPlan fp;
-        fp.nseg = c->feat_nseg;
+        fp.nseg = c->feat_nseg[0];
         for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
-            fp.m0[i] = c->feat_m0[i], fp.m1[i] = c->feat_m1[i], fp.kbeg[i] = c->feat_kbeg[i], fp.kend[i] = c->feat_kend[i],
-            fp.off[i] = c->feat_off[i];
+            fp.m0[i] = c->feat_m0[0][i], fp.m1[i] = c->feat_m1[0][i], fp.kbeg[i] = c->feat_kbeg[0][i],
+            fp.kend[i] = c->feat_kend[0][i], fp.off[i] = c->feat_off[0][i];
         fp.plan = c->d_feat_plan;
         const int nwaves = std::min(16, walk_waves);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
@@ -602,6 +787,27 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     hipLaunchKernelGGL(hp_feat_kernel, dim3((T + TS - 1) / TS, B), dim3(kFeatThreads), lds, st, mel_table(c), c->cfg.log_db, S,
                        harm, perc, harm_tmajor, K, T, TS, rows, fv, maxkeys);
     return smh::launch_status("hp_feat_kernel");
+}
+
+// single-kernel path (harm in layout 2): returns 1 if it ran, 0 if the shape does not qualify, < 0 on error
+int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, const float *perc, int B, int T, int W,
+                         int shift, int nP, float *fv, float *patches, const float *w0, float *x0p, hipStream_t st) {
+    const int K = c->K, rows = c->feat_rows;
+    if (!c->feat_walk_ok || getenv("SMH_FEAT_TAPS")) return 0;
+    if (x0p && (rows % 4 != 0 || rows > 128)) return 0;
+    const size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
+    if (lds > 158 * 1024) return 0;
+    FeatPlan fp;
+    fp.nseg = c->feat_nseg[1];
+    for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
+        fp.m0[i] = c->feat_m0[1][i], fp.m1[i] = c->feat_m1[1][i], fp.kbeg[i] = c->feat_kbeg[1][i],
+        fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
+    fp.plan = c->d_feat_plan;
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, S, harmb, perc, K, T, rows,
+                       smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
+    int rc = smh::launch_status("features_clip_kernel");
+    return rc ? rc : 1;
 }
 
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,

@@ -3,6 +3,8 @@
 //   stft -> hpss medians -> soft masks -> mel -> power_to_db -> [featuregram]
 //        -> tile-if-short -> StandardScaler per half -> extract_patches -> transpose to (N, W, F).
 // Four launches, all on the caller's stream, no host synchronisation (hipGraph-capturable).
+#include <cstdlib>
+
 #include "smh_common.h"
 #include "smh_feat.h"
 
@@ -15,7 +17,7 @@ extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const f
                                    int32_t *d_maxkeys, void *stream) {
     SMH_REQUIRE(ctx && d_S && d_harm && d_perc && d_fv && d_maxkeys, "smh_features_f32: null argument");
     SMH_REQUIRE(B >= 0 && B <= 65535 && T >= 1, "smh_features_f32: bad shape B=%d T=%d", B, T);
-    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_features_f32: harm_layout must be 0 or 1");
+    SMH_REQUIRE(harm_layout >= 0 && harm_layout <= 2, "smh_features_f32: harm_layout must be 0, 1 or 2");
     int nP = 0;
     if (d_patches) {
         SMH_REQUIRE(W >= 1 && shift >= 1, "smh_features_f32: bad patch geometry W=%d shift=%d", W, shift);
@@ -23,6 +25,13 @@ extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const f
     }
     if (B == 0) return nP;
     hipStream_t st = (hipStream_t)stream;
+    if (harm_layout == 2) {
+        int rc2 = smh_feat::launch_features_clip(ctx, d_S, d_harm, d_perc, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP, d_fv,
+                                                 nP > 0 ? d_patches : nullptr, nullptr, nullptr, st);
+        if (rc2 < 0) return rc2;
+        SMH_REQUIRE(rc2 == 1, "smh_features_ex_f32: harm_layout 2 needs smh_features_blocked_ok(ctx, T=%d, 0)", T);
+        return nP;
+    }
     int rc = smh_feat::launch_hp_feat(ctx, d_S, d_harm, d_perc, harm_layout, B, T, d_fv, (int *)d_maxkeys, st);
     if (rc) return rc;
     // always run: it applies the top_db clip that completes the featuregram
@@ -32,16 +41,36 @@ extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const f
     return nP;
 }
 
+extern "C" int smh_features_blocked_ok(const smh_ctx *ctx, int T, int with_l0) {
+    if (!ctx || T < 1) return 0;
+    const int rows = ctx->feat_rows;
+    if (!ctx->feat_walk_ok || getenv("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS")) return 0;
+    if (with_l0 && (rows % 4 != 0 || rows > 128)) return 0;
+    const size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
+    return lds <= 158 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t smh_harm_buffer_floats(int K, int T) {  // room for every harm layout of one clip
+    if (K < 1 || T < 1) return 0;
+    return (size_t)((T + 15) / 16) * 16 * K;
+}
+
 extern "C" int smh_features_l0_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc,
                                    int harm_layout, int B, int T, int W, int shift, float *d_fv, float *d_patches,
                                    const float *d_w0, float *d_x0p, int32_t *d_maxkeys, void *stream) {
     SMH_REQUIRE(ctx && d_S && d_harm && d_perc && d_fv && d_maxkeys && d_w0 && d_x0p, "smh_features_l0_f32: null argument");
     SMH_REQUIRE(B >= 0 && B <= 65535 && T >= 1, "smh_features_l0_f32: bad shape B=%d T=%d", B, T);
-    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_features_l0_f32: harm_layout must be 0 or 1");
+    SMH_REQUIRE(harm_layout >= 0 && harm_layout <= 2, "smh_features_l0_f32: harm_layout must be 0, 1 or 2");
     SMH_REQUIRE(W >= 1 && shift >= 1, "smh_features_l0_f32: bad patch geometry W=%d shift=%d", W, shift);
     const int nP = smh_num_patches(smh_tiled_frames(T, W), W, shift);
     if (B == 0 || nP <= 0) return nP;
     hipStream_t st = (hipStream_t)stream;
+    if (harm_layout == 2) {
+        int rc2 = smh_feat::launch_features_clip(ctx, d_S, d_harm, d_perc, B, T, W, shift, nP, d_fv, d_patches, d_w0, d_x0p, st);
+        if (rc2 < 0) return rc2;
+        SMH_REQUIRE(rc2 == 1, "smh_features_l0_f32: harm_layout 2 needs smh_features_blocked_ok(ctx, T=%d, 1)", T);
+        return nP;
+    }
     int rc = smh_feat::launch_hp_feat(ctx, d_S, d_harm, d_perc, harm_layout, B, T, d_fv, (int *)d_maxkeys, st);
     if (rc) return rc;
     rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)d_maxkeys, B, T, W, shift, nP, d_patches, st, d_w0, d_x0p);
@@ -60,7 +89,8 @@ extern "C" size_t smh_frontend_workspace_bytes(const smh_ctx *ctx, int B, int n_
     const int T = smh_num_frames(n_samples, ctx->cfg.n_fft, ctx->cfg.hop);
     if (T < 1) return 0;
     const size_t spec = align_up((size_t)B * ctx->K * T * sizeof(float), 256);
-    return 3 * spec + align_up((size_t)2 * B * sizeof(int), 256);
+    const size_t hspec = align_up((size_t)B * smh_harm_buffer_floats(ctx->K, T) * sizeof(float), 256);
+    return 2 * spec + hspec + align_up((size_t)2 * B * sizeof(int), 256);
 }
 
 extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, int W, int shift,
@@ -74,11 +104,12 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
         return smh::set_error(SMH_E_WORKSPACE, "smh_frontend_f32: workspace %zu < required %zu", work_bytes,
                               smh_frontend_workspace_bytes(ctx, B, n_samples));
     const size_t spec = align_up((size_t)B * ctx->K * T * sizeof(float), 256);
+    const size_t hspec = align_up((size_t)B * smh_harm_buffer_floats(ctx->K, T) * sizeof(float), 256);
     char *w = (char *)d_work;
     float *S = d_S ? d_S : (float *)w;
-    float *harm = d_harm ? d_harm : (float *)(w + spec);
-    float *perc = d_perc ? d_perc : (float *)(w + 2 * spec);
-    int32_t *maxkeys = (int32_t *)(w + 3 * spec);
+    float *perc = d_perc ? d_perc : (float *)(w + spec);
+    float *harm = d_harm ? d_harm : (float *)(w + 2 * spec);
+    int32_t *maxkeys = (int32_t *)(w + 2 * spec + hspec);
     int nP = 0;
     if (d_patches) {
         SMH_REQUIRE(W >= 1 && shift >= 1, "smh_frontend_f32: bad patch geometry W=%d shift=%d", W, shift);
@@ -89,8 +120,18 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
     int rc = smh_stft_mag_f32(ctx, d_audio, B, n_samples, S, stream);
     if (rc) return rc;
     // the harmonic median is written time-major (coalesced stores) unless the caller taps it
-    const int tm = smh_median::launch_hpss(S, B, ctx->K, T, ctx->cfg.l_harm, ctx->cfg.l_perc, harm, perc, d_harm ? 0 : 1, st);
+    // the harmonic median is written in the layout its consumer reads best unless the caller taps it:
+    // 16-frame blocks for the single-kernel feature path, time-major otherwise
+    const int want = d_harm ? 0 : (smh_features_blocked_ok(ctx, T, 0) ? 2 : 1);
+    const int tm = smh_median::launch_hpss(S, B, ctx->K, T, ctx->cfg.l_harm, ctx->cfg.l_perc, harm, perc, want, st);
     if (tm < 0) return tm;
+    if (tm == 2) {
+        rc = smh_feat::launch_features_clip(ctx, S, harm, perc, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP, d_fv,
+                                            nP > 0 ? d_patches : nullptr, nullptr, nullptr, st);
+        if (rc < 0) return rc;
+        if (rc == 1) return nP;
+        return smh::set_error(SMH_E_INVALID, "smh_frontend_f32: internal layout mismatch");
+    }
     rc = smh_feat::launch_hp_feat(ctx, S, harm, perc, tm, B, T, d_fv, (int *)maxkeys, st);
     if (rc) return rc;
     rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)maxkeys, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP,

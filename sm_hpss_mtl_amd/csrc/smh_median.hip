@@ -159,8 +159,11 @@ int launch_small(const float *S, int B, int K, int T, int w, int along_t, float 
     return smh::launch_status("median_small_kernel");
 }
 
+// harm_tmajor: 0 = (B,K,T), 1 = (B,T,K), 2 = (B, ceil(T/16), K, 16) (block-split kernels, single-tile clips only; any
+// other kernel writes layout 1 instead).  *written (optional) receives the layout that was produced.
 int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, hipStream_t st,
-           int harm_tmajor = 0) {
+           int harm_tmajor = 0, int *written = nullptr) {
+    if (written) *written = harm_tmajor;
     KernelFn fn = (lh && lp) ? find_pair_kernel(lh, lp) : find_single_kernel(lh, lp);
     if (!fn) return smh::set_error(SMH_E_INVALID, "no median kernel for (l_harm,l_perc)=(%d,%d)", lh, lp);
     Plan p;
@@ -196,6 +199,10 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
             return smh::launch_status("hpss_median_persist_kernel");
         }
     }
+    if (harm_tmajor == 2 && p.ntiles != 1) {
+        harm_tmajor = 1;
+        if (written) *written = 1;
+    }
     if (const SplitEntry *se = no_split ? nullptr : find_split_kernel(lh, lp)) {
         Plan q = p;
         if (make_split_roles(K, p.TT, lh, lp, se->threads / 64, &q)) {
@@ -205,6 +212,10 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
                                harm_tmajor, -__builtin_inff(), __builtin_inff());
             return smh::launch_status("hpss_median_split_kernel");
         }
+    }
+    if (harm_tmajor == 2) {  // the delete/insert kernel has no blocked store
+        harm_tmajor = 1;
+        if (written) *written = 1;
     }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     dim3 grid(p.ntiles, B), block((p.nwh + p.nwp) * 64);
@@ -233,8 +244,9 @@ namespace smh_median {
 int launch_hpss(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, int want_tmajor,
                 hipStream_t st) {
     if (fast_ok(T, lh) && fast_ok(K, lp) && find_pair_kernel(lh, lp)) {
-        int rc = launch(S, B, K, T, lh, lp, harm, perc, st, want_tmajor);
-        return rc ? rc : (want_tmajor ? 1 : 0);
+        int written = want_tmajor;
+        int rc = launch(S, B, K, T, lh, lp, harm, perc, st, want_tmajor, &written);
+        return rc ? rc : written;
     }
     int rc = smh_hpss_median_f32(nullptr, S, B, K, T, lh, lp, harm, perc, (void *)st);
     return rc ? rc : 0;
@@ -293,7 +305,7 @@ extern "C" int smh_hpss_median_ex_f32(const smh_ctx *, const float *d_S, int B, 
     if (rc) return rc;
     rc = check_args(d_S, B, K, T, l_perc, "smh_hpss_median_ex_f32");
     if (rc) return rc;
-    SMH_REQUIRE(harm_layout == 0 || harm_layout == 1, "smh_hpss_median_ex_f32: harm_layout must be 0 or 1");
+    SMH_REQUIRE(harm_layout >= 0 && harm_layout <= 2, "smh_hpss_median_ex_f32: harm_layout must be 0, 1 or 2");
     SMH_REQUIRE((d_harm && d_perc) || B == 0, "smh_hpss_median_ex_f32: null output");
     if (B == 0) return harm_layout;
     return smh_median::launch_hpss(d_S, B, K, T, l_harm, l_perc, d_harm, d_perc, harm_layout, (hipStream_t)stream);

@@ -178,6 +178,102 @@ __device__ __forceinline__ void split_median_walk(const float *line, int es_rt, 
     }
 }
 
+// History of a block of W-1 elements e[0..W-2]: suffix runs of size 1..W-1 (run s = sorted e[W-1-s .. W-2]).
+template <int W>
+__device__ __forceinline__ void build_history_b(const float (&e)[W - 1], float (&h)[SplitTraits<W>::HIST]) {
+    using Tr = SplitTraits<W>;
+    static_for<1, W>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const float x = e[W - 1 - s];
+        static_for<Tr::lo(s), Tr::hi(s) + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool has_below = i - 1 >= 0;
+            constexpr bool has_above = i <= s - 2;
+            constexpr int po = Tr::off(s > 1 ? s - 1 : 1), pl = Tr::lo(s > 1 ? s - 1 : 1);
+            const float below = has_below ? h[has_below ? po + (i - 1) - pl : 0] : 0.f;
+            const float above = has_above ? h[has_above ? po + i - pl : 0] : 0.f;
+            h[Tr::off(s) + i - Tr::lo(s)] = insert_slot<has_below, has_above>(below, x, above);
+        });
+    });
+}
+
+// Variant with blocks of W-1 elements: every window is (suffix of the previous block, size W-1-p) U (prefix of the
+// current one, size p+1) for p = 0 .. W-2, so block 0 only provides history and every later block yields exactly
+// W-1 outputs (16 for W = 17) -- whole float4 groups for the harmonic rows.  Harmonic outputs go to the 16-frame
+// blocked layout harm[b][t/16][k][t%16] (lanes of the feature kernel are frames: 64-byte runs per bin), written as
+// one float4 per four outputs.  `gk16` = bytes between frame groups (K*64), `kofs` = k*64.
+template <int W, int ES>
+__device__ __forceinline__ void split_median_walk_blocked(const float *line, int p0, int n_out, int n_steps, int n,
+                                                          char *obase, unsigned gk16, unsigned kofs) {
+    using Tr = SplitTraits<W>;
+    constexpr int H = W / 2, BK = W - 1;
+    float e[BK];
+    float h[Tr::HIST];
+    float pre[H + 1];
+    const int plast = p0 + n_out - 1 + H;
+    auto load_block = [&](int q0) {
+        const int lo = p0 - H + q0;
+        const bool interior = (lo >= 0) & (lo + BK <= n) & (lo + BK - 1 <= plast);
+        if (__all(interior)) {
+            const float *src = line + lo * ES;
+            static_for<0, BK>([&](auto uc) { e[decltype(uc)::value] = src[decltype(uc)::value * ES]; });
+        } else {
+            static_for<0, BK>([&](auto uc) {
+                const int pos = min(lo + decltype(uc)::value, plast);
+                e[decltype(uc)::value] = line[reflect_hi(reflect_lo(pos), n) * ES];
+            });
+        }
+    };
+    load_block(0);
+    build_history_b<W>(e, h);
+    for (int j0 = 0; j0 < n_steps; j0 += BK) {
+        load_block(j0 + BK);
+        float o4[4];
+        static_for<0, BK>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int b = p + 1, a = BK - p;
+            static_for_down<Tr::lo(b), Tr::hi(b) + 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr bool has_below = i - 1 >= 0;
+                constexpr bool has_above = i <= b - 2;
+                const float below = has_below ? pre[has_below ? i - 1 : 0] : 0.f;
+                const float above = has_above ? pre[i] : 0.f;
+                pre[i] = insert_slot<has_below, has_above>(below, e[p], above);
+            });
+            constexpr int i_lo = (H + 1 - b) > 0 ? (H + 1 - b) : 0;
+            constexpr int i_hi = a < H + 1 ? a : H + 1;
+            constexpr int ao = Tr::off(a), al = Tr::lo(a);
+            float r = 0.f;
+            static_for<i_lo, i_hi + 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float t;
+                if constexpr (i == 0) t = pre[H];
+                else if constexpr (H - i < 0) t = h[ao + (i - 1) - al];
+                else t = fmaxf(h[ao + (i - 1) - al], pre[H - i]);
+                r = (i == i_lo) ? t : fminf(r, t);
+            });
+            o4[p & 3] = r;
+            if constexpr ((p & 3) == 3 || p == BK - 1) {
+                constexpr int cnt = (p & 3) + 1, pf = p - (p & 3);
+                const int j = j0 + pf, t = p0 + j;  // first frame of the chunk
+                char *dst = obase + (unsigned)(t >> 4) * gk16 + kofs + (unsigned)(t & 15) * 4u;
+                if (cnt == 4 && (t & 3) == 0 && j + 3 < n_out) {
+                    float4u v = {o4[0], o4[1], o4[2], o4[3]};
+                    *reinterpret_cast<float4u *>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < cnt; ++c) {
+                        const int tc = t + c;
+                        if (j + c < n_out)
+                            *reinterpret_cast<float *>(obase + (unsigned)(tc >> 4) * gk16 + kofs + (unsigned)(tc & 15) * 4u) = o4[c];
+                    }
+                }
+            }
+        });
+        if (j0 + BK < n_steps) build_history_b<W>(e, h);
+    }
+}
+
 // Register budget: the history is H*(H+1)-1 registers (80 for W = 17, 120 for W = 21), so the workgroup size is
 // chosen for 4 waves per SIMD (128 VGPRs) up to W = 17 and 3 waves per SIMD (168 VGPRs) above; two workgroups share
 // a CU (LDS: 2 x 80 KB), one staging its tile while the other computes.
@@ -285,7 +381,11 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
                 if (ts < te) {
                     const float *row = tile + k * stride - c0;
                     char *ob = reinterpret_cast<char *>(harm + (size_t)b * K * T);
-                    if (harm_tmajor)
+                    if (harm_tmajor == 2)  // (B, ceil(T/16), K, 16): the clip's image is ceil(T/16)*K*16 floats
+                        split_median_walk_blocked<LH, 1>(row, ts, te - ts, seglen, T,
+                                                         reinterpret_cast<char *>(harm + (size_t)b * ((T + 15) >> 4) * K * 16),
+                                                         (unsigned)K * 64u, (unsigned)k * 64u);
+                    else if (harm_tmajor)
                         split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
                                                                 (unsigned)(ts * K + k) * 4u, (unsigned)K * 4u);
                     else
@@ -370,7 +470,11 @@ hpss_median_persist_kernel(const float *__restrict__ S, float *__restrict__ harm
                 if (ts < te) {
                     const float *row = tile + k * T;
                     char *ob = reinterpret_cast<char *>(harm + (size_t)b * K * T);
-                    if (harm_tmajor)
+                    if (harm_tmajor == 2)  // (B, ceil(T/16), K, 16): the clip's image is ceil(T/16)*K*16 floats
+                        split_median_walk_blocked<LH, 1>(row, ts, te - ts, seglen, T,
+                                                         reinterpret_cast<char *>(harm + (size_t)b * ((T + 15) >> 4) * K * 16),
+                                                         (unsigned)K * 64u, (unsigned)k * 64u);
+                    else if (harm_tmajor)
                         split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
                                                                 (unsigned)(ts * K + k) * 4u, (unsigned)K * 4u);
                     else

@@ -11,7 +11,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST
 python3 - "$R" <<'PY'
 import csv, glob, json, collections, sys
 R = sys.argv[1]
-short = {"stft": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat": "hp_feat", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
+short = {"stft": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat": "hp_feat", "features_clip_kernel": "features_clip", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
 def key(name):
     for k, v in short.items():
         if k in name: return v

@@ -14,7 +14,9 @@ layout = int(os.environ.get("LAYOUT", 1))
 fe = Frontend(FrontendConfig(l_harm=lh, l_perc=lp))
 audio = torch.from_numpy(np.tile(synth_clips(64, seed=1), (B // 64, 1))).cuda()
 S = fe.stft_mag(audio)
-harm, perc = torch.empty_like(S), torch.empty_like(S)
+T_ = S.shape[2]
+harm = torch.empty((B, ((T_ + 15) // 16) * 16 * fe.K), device=S.device)  # large enough for every layout
+perc = torch.empty_like(S)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 run = lambda: _lib.check(fe.lib.smh_hpss_median_ex_f32(fe._h, p(S), B, fe.K, S.shape[2], lh, lp, p(harm), p(perc), layout, st))
@@ -28,3 +30,10 @@ b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / iters
 print("layout=%d " % layout + "(%d,%d) B=%d: %.4f ms -> %.1f%% of 8 TB/s" % (lh, lp, B, ms, 100 * 3 * 201 * 98 * 4 * B / (ms * 1e-3) / 8e12), flush=True)
+
+if layout == 2:  # decode (B, T/16, K, 16) and compare with the (B, K, T) result of the parity entry point
+    G = (T_ + 15) // 16
+    got = harm.view(B, G, fe.K, 16).permute(0, 2, 1, 3).reshape(B, fe.K, G * 16)[:, :, :T_]
+    ref, _ = fe.hpss_median(S[:8], lh, lp)
+    torch.cuda.synchronize()
+    print("layout 2 decode equals (B,K,T):", bool(torch.equal(got[:8], ref)), flush=True)
