@@ -651,27 +651,48 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
     }
     // clip in LDS, write the final featuregram (coalesced rows)
     float *g = fv + (size_t)b * R2 * T;
-    for (int r = wave; r < R2; r += nw) {
-        const float thr = r < rows ? thrH : thrP;
-        for (int t = lane; t < T; t += 64) {
-            const float x = fmaxf(img[r * ld + t], thr);
-            img[r * ld + t] = x;
-            g[(size_t)r * T + t] = x;
+    if ((T & 1) == 0) {  // rows start on 8-byte boundaries: one float2 per lane, a 98-frame row is one instruction
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        for (int r = wave; r < R2; r += nw) {
+            const float thr = r < rows ? thrH : thrP;
+            for (int t2 = lane; t2 < T / 2; t2 += 64) {
+                const float x0 = fmaxf(img[r * ld + 2 * t2], thr), x1 = fmaxf(img[r * ld + 2 * t2 + 1], thr);
+                img[r * ld + 2 * t2] = x0;
+                img[r * ld + 2 * t2 + 1] = x1;
+                f32x2 v = {x0, x1};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(g + (size_t)r * T) + t2);
+            }
+        }
+    } else {
+        for (int r = wave; r < R2; r += nw) {
+            const float thr = r < rows ? thrH : thrP;
+            for (int t = lane; t < T; t += 64) {
+                const float x = fmaxf(img[r * ld + t], thr);
+                img[r * ld + t] = x;
+                g[(size_t)r * T + t] = x;
+            }
         }
     }
     __syncthreads();
     if ((!patches && !x0p) || nP <= 0) return;
     // StandardScaler statistics: one thread per row, f64 (see std_patch_kernel)
-    for (int r = threadIdx.x; r < R2; r += blockDim.x) {
-        const float *row = img + r * ld;
+    for (int r0 = 0; r0 < R2; r0 += (int)(blockDim.x >> 2)) {  // four lanes per row, f64 partial sums
+        const int r = r0 + (int)(threadIdx.x >> 2), sub = threadIdx.x & 3;
+        const bool on = r < R2;
+        const float *row = img + (on ? r : 0) * ld;
         double sum = 0.0;
-        for (int t = 0; t < T; ++t) sum += (double)row[t];
+        for (int t = sub; t < T; t += 4) sum += (double)row[t];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
         const double mean = sum / (double)T;
         double qv = 0.0;
-        for (int t = 0; t < T; ++t) {
+        for (int t = sub; t < T; t += 4) {
             const double dlt = (double)row[t] - mean;
             qv += dlt * dlt;
         }
+        qv += __shfl_xor(qv, 1);
+        qv += __shfl_xor(qv, 2);
+        if (!on || sub != 0) continue;
         const double var = qv / (double)T;
         const double eps = 2.220446049250313e-16;
         const double nm = (double)T * mean * eps;
@@ -686,7 +707,7 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
     if (x0p) {  // the network's first layer, per clip half (std_patch_kernel<true> has the derivation)
         const int q = lane >> 4, j = lane & 15;
         const int ut = (W + 15) >> 4;
-        constexpr int kG = 8;
+        constexpr int kMaxSt = 32;  // rows <= 128: every weight of the task is requested before the first product
         for (int task = wave; task < nP * ut * 4; task += nw) {
             const int mt = task & 1, half = (task >> 1) & 1, pu = task >> 2;
             const int p = pu / ut, u = pu - p * ut;
@@ -699,21 +720,21 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
             const float *wr = w0 + ((size_t)half * rows + q) * 32 + 16 * mt + j;
             const float *tl = img + (size_t)half * rows * ld;
             const float *mh = s_mean + half * rows, *ml = s_lo + half * rows, *iv = s_inv + half * rows;
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
             const int nst = rows / 4;
-            for (int s0 = 0; s0 < nst; s0 += kG) {
-                float wa[kG];
+            float wa[kMaxSt];
 #pragma unroll
-                for (int gI = 0; gI < kG; ++gI) wa[gI] = wr[(size_t)(4 * min(s0 + gI, nst - 1)) * 32];
+            for (int st = 0; st < kMaxSt; ++st) wa[st] = wr[(size_t)(4 * min(st, nst - 1)) * 32];
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};  // two chains: MFMA latency > issue
 #pragma unroll
-                for (int gI = 0; gI < kG; ++gI) {
-                    if (s0 + gI < nst) {
-                        const int r = 4 * (s0 + gI) + q;
-                        const float c = (float)((double)tl[r * ld + tt] - ((double)mh[r] + (double)ml[r]));
-                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[gI], c * iv[r], c0, 0, 0, 0);
-                    }
+            for (int st = 0; st < kMaxSt; ++st) {
+                if (st < nst) {
+                    const int r = 4 * st + q;
+                    const float c = (float)((double)tl[r * ld + tt] - ((double)mh[r] + (double)ml[r]));
+                    if (st & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st], c * iv[r], c1, 0, 0, 0);
+                    else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st], c * iv[r], c0, 0, 0, 0);
                 }
             }
+            c0 += c1;
             if (jt < W)
                 *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 16 * mt + 4 * q) = c0;
         }
