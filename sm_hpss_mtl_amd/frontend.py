@@ -207,6 +207,8 @@ class Frontend:
         Feed x0p to `model.forward_from_x0`.  Same logits as features -> forward_device within f32 tolerance."""
         S, harm, perc = _f32c(S, "S"), _f32c(harm, "harm"), _f32c(perc, "perc")
         B, K, T = S.shape
+        if int(harm_layout) == 2 and harm.numel() < B * self.lib.smh_harm_buffer_floats(K, T):
+            raise ValueError("harm_layout 2 needs smh_harm_buffer_floats(K, T) floats per clip")
         if model.n_feat != 2 * self.rows or model.patch_size != W:
             raise ValueError("model expects (W=%d, n_feat=%d), the front end produces (W=%d, n_feat=%d)"
                              % (model.patch_size, model.n_feat, W, 2 * self.rows))

@@ -419,3 +419,39 @@ def test_layer0_fused_into_features_matches_the_two_step_path(fe, clips4, W, shi
     assert float((got - ref).abs().max()) <= 2e-5
     oracle = np.concatenate(b3_mtl.forward(host(two["patches"]), w, ncls), axis=1)
     assert np.max(np.abs(host(got) - oracle)) <= 1e-4
+
+
+@pytest.mark.parametrize("W,shift,ncls", [(68, 68, 3), (68, 5, 3), (99, 34, 5)])
+def test_single_feature_kernel_on_blocked_harm_matches_the_two_step_path(fe, clips4, W, shift, ncls):
+    """The bench fast path end to end: median with harm_layout = 2 (16-frame blocks) -> features_clip_kernel with the
+    layer-0 partials -> smh_model_forward_x0_f32, against (B,K,T) medians -> features -> patches -> forward."""
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    from sm_hpss_mtl_amd.model import B3MTL
+    w = b3_mtl.init_weights(seed=5, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls, seed=0)
+    m.set_weights_dict(w)
+    S = fe.stft_mag(dev(clips4))
+    B, K, T = S.shape
+    harm0, perc0 = fe.hpss_median(S)
+    two = fe.features(S, harm0, perc0, W=W, shift=shift)
+    ref = m.forward_device(two["patches"])
+    assert fe.lib.smh_features_blocked_ok(fe._h, T, 1) == 1
+    harm2 = torch.empty((B, fe.lib.smh_harm_buffer_floats(K, T)), device="cuda")
+    perc2 = torch.empty_like(S)
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lay = _lib.check(fe.lib.smh_hpss_median_ex_f32(fe._h, ptr(S), B, K, T, fe.cfg.l_harm, fe.cfg.l_perc, ptr(harm2), ptr(perc2), 2, st))
+    assert lay == 2 and torch.equal(perc2, perc0)
+    G = (T + 15) // 16
+    dec = harm2.view(B, G, K, 16).permute(0, 2, 1, 3).reshape(B, K, G * 16)[:, :, :T]
+    assert torch.equal(dec, harm0)  # bit-exact medians in the blocked layout
+    fused = fe.features_l0(S, harm2, perc2, 2, W, shift, m, patches=True)
+    got = m.forward_from_x0(fused["x0p"])
+    torch.cuda.synchronize()
+    assert fused["n_patches"] == two["n_patches"]
+    assert float((fused["fv"] - two["fv"]).abs().max()) <= 1e-4       # dB: other summation order over the taps
+    assert float((fused["patches"] - two["patches"]).abs().max()) <= 1e-4
+    assert float((got - ref).abs().max()) <= 5e-5
+    oracle = np.concatenate(b3_mtl.forward(host(two["patches"]), w, ncls), axis=1)
+    assert np.max(np.abs(host(got) - oracle)) <= 1e-4
