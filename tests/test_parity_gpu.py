@@ -455,3 +455,36 @@ def test_single_feature_kernel_on_blocked_harm_matches_the_two_step_path(fe, cli
     assert float((got - ref).abs().max()) <= 5e-5
     oracle = np.concatenate(b3_mtl.forward(host(two["patches"]), w, ncls), axis=1)
     assert np.max(np.abs(host(got) - oracle)) <= 1e-4
+
+
+def test_frontend_randomised_lengths_and_feature_names():
+    """12 seeded draws of (clip length, feature name, n_fft, windows, patch geometry): odd sample counts (generic STFT
+    kernel), T below and above one wave, every featName of SURVEY 8a (mel / no mel, dB / magnitude), Jang's n_fft = 512;
+    featuregram and patches from the fused entry point against the oracle."""
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig, FEATS
+    from sm_hpss_mtl_amd.synth import synth_clips
+    rng = np.random.default_rng(7)
+    names = sorted(FEATS)
+    for trial in range(12):
+        name = names[trial % 4]
+        use_mel, log = FEATS[name]
+        n_fft = 512 if (trial % 6 == 5) else 400
+        n = int(rng.integers(3000, 30000)) | (trial & 1)           # odd lengths every other trial
+        lh, lp = [(21, 11), (17, 17), (11, 21), (5, 31)][trial % 4]
+        W, shift = [(68, 34), (20, 7), (99, 50)][trial % 3]
+        cfg = FrontendConfig(n_fft=n_fft, win_length=400, n_mels=120 if use_mel else 0, l_harm=lh, l_perc=lp, log_db=log)
+        fe_t = Frontend(cfg)
+        y = synth_clips(2, seed=100 + trial, n_samples=n)
+        res = fe_t.run(dev(y), W=W, shift=shift)
+        fv, patches = host(res["fv"]), host(res["patches"])
+        T = 1 + (n - n_fft) // 160
+        rows = 120 if use_mel else n_fft // 2 + 1
+        assert fv.shape == (2, 2 * rows, T), (trial, fv.shape)
+        for i in range(2):
+            ref = ofe.featuregram(y[i], name, n_fft=n_fft, n_mels=120, l_harm=lh, l_perc=lp)
+            tol = 2e-3 if log else 2e-5 * max(1.0, float(np.abs(ref).max()))
+            assert np.max(np.abs(fv[i] - ref)) <= tol, (trial, name, n, float(np.max(np.abs(fv[i] - ref))))
+            nP = res["n_patches"]
+            refp = ofe.tcn_input(ofe.feature_patches(fv[i], W, shift, name))  # from the GPU's own fv
+            assert refp.shape[0] == nP
+            np.testing.assert_allclose(patches[i * nP:(i + 1) * nP], refp, atol=2e-4)
