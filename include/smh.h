@@ -183,6 +183,15 @@ int smh_mix_signals_f32(const float *d_sp, const float *d_mu, int B, int N, int 
  * Bit-exact selection.  d_y must not alias d_x.                                                                 */
 int smh_medfilt1d_f32(const float *d_x, int B, int n, int kernel_size, float *d_y, void *stream);
 
+/* ---- the other two functions of lib/cython_impl/tools.pyx (off by default on the hot path), float64 like the reference:
+ * scale_data(FV, mean, stdev) :138-165 -> (FV - mean[f]) / (stdev[f] + 1e-10), FV (F, T);
+ * get_data_statistics(FV, stat_type, axis) :169-215 for patches (N, F, T): stat 0 mean, 1 variance (population),
+ * 2 skew, 3 kurtosis (scipy.stats, biased, Fisher); axis 0 reduces over the rows -> (N, T), axis 1 over the frames ->
+ * (N, F).                                                                                                            */
+int smh_scale_data_f64(const double *d_FV, int F, int T, const double *d_mean, const double *d_stdev, double *d_out,
+                       void *stream);
+int smh_data_statistics_f64(const double *d_FV, int N, int F, int T, int stat, int axis, double *d_out, void *stream);
+
 /* ---- a10-a12: B3_MTL = get_Lemaire_MTL_model (lib/proposed_architectures.py:85-170, 25-80) ---- */
 typedef struct smh_model_cfg {
     int32_t n_feat;     /* N_MELS argument = input_shape[1]: 240                       */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "smh_preprocess_signal_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _sz, _vp]),
     "smh_mix_signals_f32": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_medfilt1d_f32": (_i, [_fp, _i, _i, _i, _fp, _vp]),
+    "smh_scale_data_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "smh_data_statistics_f64": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "smh_model_destroy": (None, [_vp]),
     "smh_model_num_params": (_sz, [_vp]),

@@ -3,8 +3,8 @@
 `extract_patches` (tools.pyx:21-38) is on the hot path and runs as a HIP gather through the C ABI
 (`smh_extract_patches_f32`); it returns float64 (nP, F, W) exactly like the Cython function.
 `removeSilence` (tools.pyx:42-134) runs through `smh_remove_silence_f32`; `scale_data` /
-`get_data_statistics` are out of scope (off by default in the reference: frame_level_scaling False,
-skewness_vector None).
+`get_data_statistics` (:138-215; off by default in the reference: frame_level_scaling False, skewness_vector None)
+are float64 device kernels (`smh_scale_data_f64`, `smh_data_statistics_f64`).
 """
 from __future__ import annotations
 
@@ -67,9 +67,49 @@ def removeSilence(Xin, nSamples, energy, nFrames, fs, Tw, Ts, alpha=0.025, beta=
     return Xin, sample_silMarker, frame_silMarker, totalSilDuration
 
 
-def scale_data(*args, **kwargs):
-    raise NotImplementedError("tools.scale_data is out of scope (frame_level_scaling is False on the hot path)")
+def _stream():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def get_data_statistics(*args, **kwargs):
-    raise NotImplementedError("tools.get_data_statistics is out of scope (skewness_vector is None on the hot path)")
+def scale_data(FV, mean, stdev):
+    """tools.pyx:138-165 -> float64 (F, T): (FV - mean[f]) / (stdev[f] + 1e-10)."""
+    import ctypes as C
+    from ... import _lib
+    lib = _lib.require_gpu()
+    FV = np.asarray(FV)
+    if FV.ndim != 2:
+        raise ValueError("scale_data: FV should be (num_features, num_frames), got %s" % (FV.shape,))
+    F, T = FV.shape
+    mean, stdev = np.asarray(mean, np.float64).ravel(), np.asarray(stdev, np.float64).ravel()
+    if mean.size != F or stdev.size != F:
+        raise ValueError("scale_data: mean / stdev need one value per feature row (%d), got %d / %d" % (F, mean.size, stdev.size))
+    d = torch.from_numpy(np.ascontiguousarray(FV, dtype=np.float64)).cuda()
+    dm, ds = torch.from_numpy(mean).cuda(), torch.from_numpy(stdev).cuda()
+    out = torch.empty_like(d)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.smh_scale_data_f64(p(d), F, T, p(dm), p(ds), p(out), _stream()), "smh_scale_data_f64")
+    return out.cpu().numpy()
+
+
+def get_data_statistics(FV, stat_type='skew', axis=0):
+    """tools.pyx:169-215: FV (N, f, t) -> (N, t) for axis=0 (along the columns) or (N, f) for axis=1."""
+    import ctypes as C
+    from ... import _lib
+    lib = _lib.require_gpu()
+    stats = {'mean': 0, 'variance': 1, 'skew': 2, 'kurtosis': 3}
+    if stat_type not in stats:
+        raise ValueError("get_data_statistics: stat_type must be one of %s" % sorted(stats))
+    if axis not in (0, 1):
+        raise ValueError("get_data_statistics: axis must be 0 or 1")
+    FV = np.asarray(FV)
+    if FV.ndim == 4 and FV.shape[3] == 1:
+        FV = FV[..., 0]
+    if FV.ndim != 3:
+        raise ValueError("get_data_statistics: FV should be (N, f, t), got %s" % (FV.shape,))
+    N, F, T = FV.shape
+    d = torch.from_numpy(np.ascontiguousarray(FV, dtype=np.float64)).cuda()
+    out = torch.empty((N, T if axis == 0 else F), dtype=torch.float64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.smh_data_statistics_f64(p(d), N, F, T, stats[stat_type], axis, p(out), _stream()), "smh_data_statistics_f64")
+    return out.cpu().numpy()

@@ -219,3 +219,35 @@ def test_oracle_medfilt_vs_scipy(n, k):
     x = np.random.default_rng(n + k).random(n).astype(np.float32)
     x[::7] = x[0]
     assert np.array_equal(oinf.medfilt(x, k), ss.medfilt(x, k))
+
+
+def test_scale_data_vs_compiled_reference():
+    from oracle import tools_stats
+    tools = _ref_tools()
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        FV = rng.normal(size=(42, 68)).astype(dt) * 7 - 3
+        mean, std = FV.mean(axis=1), FV.std(axis=1)
+        ref = tools.scale_data(FV, mean, std)
+        got = tools_stats.scale_data(FV, mean, std)
+        assert got.dtype == ref.dtype == np.float64 and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("stat", ["mean", "variance", "skew", "kurtosis"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_data_statistics_vs_compiled_reference(stat, axis):
+    from oracle import tools_stats
+    tools = _ref_tools()
+    rng = np.random.default_rng(11)
+    FV = rng.gamma(2.0, size=(5, 21, 34)) - rng.normal(size=(5, 21, 34)) ** 2
+    ref = tools.get_data_statistics(FV, stat_type=stat, axis=axis)
+    got = tools_stats.get_data_statistics(FV, stat, axis)
+    assert got.shape == ref.shape == (5, 34 if axis == 0 else 21)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+
+
+def test_data_statistics_constant_rows():
+    from oracle import tools_stats
+    FV = np.ones((2, 4, 6))
+    assert np.all(tools_stats.get_data_statistics(FV, "skew", 0) == 0.0)
+    assert np.all(tools_stats.get_data_statistics(FV, "kurtosis", 1) == -3.0)
