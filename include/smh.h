@@ -265,6 +265,28 @@ size_t smh_cnn_workspace_bytes(const smh_cnn *m, int N);
 int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
                         size_t work_bytes, void *stream);
 
+/* ---- a13 / a14: training step of the Conv2D MTL baselines (what model.fit runs per batch for the models compiled at
+ * lib/proposed_architectures.py:499-506 / :572-580 / :750-757).  Built for SMH_CNN_DOUKHAN; the other two kinds are
+ * refused at creation.  The trainer owns its activations, gradients and optimiser state (sized for max_batch).
+ *   d_x (N, H, W) images; d_y (N, out_dim) targets laid out like the forward output [S | M | (N) | R | 3C one-hot]
+ *   d_drop: Dropout masks (0 or 1/(1-rate)) of the trunk, one (N, dim_i) block per Dropout layer in graph order
+ *           (smh_cnn_trainer_num_dropouts / _dropout_info give dim_i and rate_i), or NULL (no dropout)
+ *   d_drop_heads (N, n_heads, 16) Dropout(0.4) masks of the heads or NULL; h_loss_weights: n_heads + 1 host floats or NULL
+ *   d_losses: n_heads + 4 floats out = [per-head losses..., 3C loss, weighted sum (without l2), 3C accuracy, l2 penalty]
+ * smh_cnn_trainer_apply_f32: g = grad * grad_scale (+ l2 term); optimizer 0 = SGD (beta1 = momentum), 1 = Adam
+ * (Keras: w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)); BatchNorm moving statistics <- 0.99*old + 0.01*batch;
+ * the inference epilogues of smh_cnn_forward_f32 are re-folded from the new weights.                              */
+typedef struct smh_cnn_trainer smh_cnn_trainer;
+int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer **out);
+void smh_cnn_trainer_destroy(smh_cnn_trainer *t);
+float *smh_cnn_trainer_grad_ptr(smh_cnn_trainer *t);
+int smh_cnn_trainer_num_dropouts(const smh_cnn_trainer *t);
+int smh_cnn_trainer_dropout_info(const smh_cnn_trainer *t, int i, size_t *dim, float *rate);
+int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop,
+                           const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream);
+int smh_cnn_trainer_apply_f32(smh_cnn_trainer *t, int optimizer, float lr, float beta1, float beta2, float eps,
+                              float grad_scale, void *stream);
+
 /* ---- a14: one training step = what model.fit runs per batch (Proposed_Work_Results.py:298-307) for the
  * model compiled at lib/proposed_architectures.py:156-165: BCE (S, M[, N]) + MSE (R) + CCE (3C) with optional
  * loss_weights, l2(0.01) on the Dense(16) kernels, SGD(momentum, clipnorm, lr from ExponentialDecay).

@@ -67,6 +67,13 @@ SIGNATURES = {
     "smh_preprocess_signal_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _sz, _vp]),
     "smh_mix_signals_f32": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_medfilt1d_f32": (_i, [_fp, _i, _i, _i, _fp, _vp]),
+    "smh_cnn_trainer_create": (_i, [_vp, _i, C.POINTER(C.c_void_p)]),
+    "smh_cnn_trainer_destroy": (None, [_vp]),
+    "smh_cnn_trainer_grad_ptr": (_vp, [_vp]),
+    "smh_cnn_trainer_num_dropouts": (_i, [_vp]),
+    "smh_cnn_trainer_dropout_info": (_i, [_vp, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
+    "smh_cnn_train_step_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "smh_cnn_trainer_apply_f32": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "smh_scale_data_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "smh_data_statistics_f64": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "smh_model_create": (_i, [C.POINTER(ModelCfg), C.POINTER(_vp)]),

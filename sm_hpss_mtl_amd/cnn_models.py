@@ -6,7 +6,8 @@
 
 The layer graph, the parameter table (names, Keras shapes, order) and all arithmetic live in libsmh.so
 (csrc/smh_cnn.hip); this class only keeps the host copy of the weights, initialises them the way the reference's
-initialisers do, and moves tensors.  Inference only: training of the baselines is not built.
+initialisers do, and moves tensors.  Training (`fit` / `train_on_batch` / `evaluate`, cnn_training.py over
+`smh_cnn_train_step_f32`) is built for the Doukhan model; the other two raise NotImplementedError there.
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .cnn_training import CnnTrainingMixin
 from .model import head_spec
 
 KINDS = {"Doukhan": 0, "Papakostas": 1, "Jang": 2}
@@ -25,10 +27,11 @@ KINDS = {"Doukhan": 0, "Papakostas": 1, "Jang": 2}
 LEARNING_RATE = {"Doukhan": 0.0001, "Papakostas": 0.001, "Jang": 0.001}
 
 
-class CnnMTL:
-    """`model` object of get_{Doukhan,Papakostas,Jang}_MTL_model for inference."""
+class CnnMTL(CnnTrainingMixin):
+    """`model` object of get_{Doukhan,Papakostas,Jang}_MTL_model."""
 
-    def __init__(self, kind, input_shape, n_classes=3, seed=None, n_mels=120, n_fft=512, fs=16000, fc_width=0):
+    def __init__(self, kind, input_shape, n_classes=3, seed=None, n_mels=120, n_fft=512, fs=16000, fc_width=0,
+                 loss_weights=None):
         if kind not in KINDS:
             raise ValueError("kind must be one of %s" % sorted(KINDS))
         self.lib = _lib.require_gpu()
@@ -56,8 +59,15 @@ class CnnMTL:
         self._init_weights(np.random.default_rng(seed))
         assert self.count_params() == self.lib.smh_cnn_num_params(self._h)
         self._dirty = True
+        self._device_newer = False
+        self.loss_weights = loss_weights
+        self._init_training_state()
 
     def __del__(self):
+        tr = getattr(self, "_trainer", None)
+        if tr:
+            self.lib.smh_cnn_trainer_destroy(tr)
+            self._trainer = None
         h = getattr(self, "_h", None)
         if h:
             self.lib.smh_cnn_destroy(h)
@@ -122,10 +132,23 @@ class CnnMTL:
     def weight_names(self):
         return [n for n, _, _ in self._spec]
 
+    def _pull_weights(self):
+        """After training steps the device copy is the master: refresh the host dict from it."""
+        if self._device_newer:
+            flat = np.empty(self.count_params(), np.float32)
+            _lib.check(self.lib.smh_cnn_get_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "smh_cnn_get_weights")
+            for name, shape, off in self._spec:
+                self.weights[name] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
+            self._device_newer = False
+
     def get_weights(self):
+        self._pull_weights()
         return [self.weights[n].copy() for n, _, _ in self._spec]
 
     def get_weights_dict(self):
+        self._pull_weights()
         return self.weights
 
     def set_weights(self, arrays):
@@ -138,11 +161,13 @@ class CnnMTL:
                 raise ValueError("set_weights: %s expects shape %s, got %s" % (name, shape, a.shape))
             self.weights[name] = a.copy()
         self._dirty = True
+        self._device_newer = False
 
     def set_weights_dict(self, d):
         self.set_weights([d[n] for n, _, _ in self._spec])
 
     def save_weights(self, path):
+        self._pull_weights()
         np.savez(path if str(path).endswith(".npz") else str(path) + ".npz",
                  **{k.replace("/", "__"): v for k, v in self.weights.items()})
 
@@ -161,12 +186,6 @@ class CnnMTL:
         for name, shape, _ in self._spec:
             print_fn("  %-40s %-22s %d" % (name, str(tuple(shape)), int(np.prod(shape))))
         print_fn("Total params: %d" % self.count_params())
-
-    def _no_training(self, *a, **k):
-        raise NotImplementedError("training of the Conv2D MTL baselines is not built (inference forward only); "
-                                  "train B3_MTL (get_Lemaire_MTL_model) or load trained weights with set_weights")
-
-    fit = evaluate = train_on_batch = _no_training
 
     # ---- inference -----------------------------------------------------------------------------------------------
     def _sync_weights(self):

@@ -33,6 +33,20 @@ struct TrainIO {
     float *pre;             // (N, kPS): Dense-on-trunk outputs incl. bias (3C logits | head Dense(16)s)
 };
 
+// heads_train_kernel (smh_train.hip): batch-statistics BN, Dropout, the four losses and d loss / d pre for the '3C'
+// softmax and the MTL heads, from the Dense-on-features outputs `pre` (N, kPS) = [3C logits | Dense(16) per head].
+// Shared by the B3_MTL trainer and the Conv2D baselines' trainer (smh_cnn_train.hip).
+struct HeadsArgs {
+    int N, D, NH, n_classes, n_heads, out_dim;
+    int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
+    float lw[kMaxHeads + 1];
+    size_t goff_head[kMaxHeads];  // canonical offset of each head's first tensor (dense kernel) in `grad`
+    size_t goff_c3b;              // canonical offset of the 3C bias
+    size_t hp_off[kMaxHeads];     // offset in `hp` of each head's [gamma, beta, mean, var (16 each), out kernel, out bias]
+};
+int launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop, float *dpre,
+                       float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st);
+
 }  // namespace smh_tcn
 
 struct smh_model {

@@ -27,13 +27,7 @@ constexpr int kBG = 1;        // patches per workgroup in the backward kernel
 constexpr int kBS = 33;       // LDS row stride (floats) of the backward buffers
 constexpr int kBThreads = 1024;
 
-struct HeadsArgs {
-    int N, D, NH, n_classes, n_heads, out_dim;
-    int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
-    float lw[kMaxHeads + 1];
-    size_t goff_head[kMaxHeads];  // canonical offset of each head's first tensor (dense kernel)
-    size_t goff_c3b;              // canonical offset of the 3C bias
-};
+using smh_tcn::HeadsArgs;
 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -93,12 +87,9 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     // B: one head at a time, lanes over the samples: forward through BN / relu / dropout / output Dense, loss,
     // gradients; sums over the batch are wave-reduced before they touch LDS
     for (int h = 0; h < nh; ++h) {
-        const float *ph = hp;
+        const float *ph = hp + a.hp_off[h];
         int col = 0;
-        for (int k = 0; k < h; ++k) {
-            ph += 4 * kHidden + kHidden * a.head_odim[k] + a.head_odim[k];
-            col += a.head_odim[k];
-        }
+        for (int k = 0; k < h; ++k) col += a.head_odim[k];
         const float *gamma = ph, *beta = ph + 16, *wo = ph + 64;
         const int od = a.head_odim[h];
         const float *bo = wo + kHidden * od;
@@ -788,6 +779,12 @@ __global__ void seg_sgd_kernel(const Segment *__restrict__ segs, float *__restri
 
 }  // namespace
 
+int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop,
+                                float *dpre, float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st) {
+    hipLaunchKernelGGL(heads_train_kernel, dim3(1), dim3(1024), 0, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+    return smh::launch_status("heads_train_kernel");
+}
+
 struct smh_trainer {
     smh_model *m;
     int max_batch, nseg;
@@ -879,9 +876,12 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (h_loss_weights)
         for (int i = 0; i <= m->n_heads; ++i) ha.lw[i] = h_loss_weights[i];
     ha.goff_c3b = off.c3_b;
-    hipLaunchKernelGGL(heads_train_kernel, dim3(1), dim3(1024), 0, st, ha, t->d_pre, d_y, m->d_hp, d_drop_heads, t->d_dpre,
-                       t->d_dxh, t->d_grad, t->d_bnstat, d_losses);
-    rc = smh::launch_status("heads_train_kernel");
+    size_t hpo = 0;
+    for (int i = 0; i < m->n_heads; ++i) {  // d_hp: per head [gamma, beta, mean, var, out kernel, out bias], packed
+        ha.hp_off[i] = hpo;
+        hpo += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
+    }
+    rc = launch_heads_train(ha, t->d_pre, d_y, m->d_hp, d_drop_heads, t->d_dpre, t->d_dxh, t->d_grad, t->d_bnstat, d_losses, st);
     if (rc) return rc;
     BwdArgs ba;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;

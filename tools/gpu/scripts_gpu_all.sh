@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
-timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -25 gpurun_out/pytest_gpu.log
+timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -25 gpurun_out/pytest_gpu.log
 if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 400 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -2 gpurun_out/bench.log
 rm -rf gpurun_out/prof/trace
