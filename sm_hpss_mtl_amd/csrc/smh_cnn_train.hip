@@ -29,10 +29,12 @@ constexpr int kMaxRed = 1024;  // row chunks of a column reduction
 // ---- column reductions over a row-major (M x C) matrix ---------------------------------------------------------
 // F = 0: sum z           F = 1: sum (z - mean)^2          F = 2: g = relu'/dropout of dA; sums of g and g * xhat
 struct RedArgs {
-    const float *z, *a, *dA, *mask, *mean, *rstd;
+    const float *z, *dA, *mask, *mean, *rstd, *gamma, *beta;
     size_t M;
     int C, rows_per_block;
 };
+// the ReLU gate is re-derived from z with the forward's own expression (bitwise the same value), so the activation
+// itself is not read again
 template <int F>
 __device__ __forceinline__ void red_item(const RedArgs &r, size_t i, int c, float &v0, float &v1) {
     if (F == 0) {
@@ -41,36 +43,64 @@ __device__ __forceinline__ void red_item(const RedArgs &r, size_t i, int c, floa
         const float d = r.z[i] - r.mean[c];
         v0 = fmaf(d, d, v0);
     } else {
-        const float g = r.a[i] > 0.f ? r.dA[i] * (r.mask ? r.mask[i] : 1.f) : 0.f;
+        const float xh = (r.z[i] - r.mean[c]) * r.rstd[c];
+        const float g = fmaf(xh, r.gamma[c], r.beta[c]) > 0.f ? r.dA[i] * (r.mask ? r.mask[i] : 1.f) : 0.f;
         v0 += g;
-        v1 = fmaf(g, (r.z[i] - r.mean[c]) * r.rstd[c], v1);
+        v1 = fmaf(g, xh, v1);
+    }
+}
+// four channels per thread (C % 4 == 0, 256 % (C/4) == 0): 16-byte loads, 256 / (C/4) rows per pass
+template <int F>
+__device__ __forceinline__ void red_item4(const RedArgs &r, size_t i, int c, f32x4 &v0, f32x4 &v1) {
+    const f32x4 z = *reinterpret_cast<const f32x4 *>(r.z + i);
+    if (F == 0) {
+        v0 += z;
+    } else {
+        const f32x4 mean = *reinterpret_cast<const f32x4 *>(r.mean + c);
+        const f32x4 d = z - mean;
+        if (F == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v0[q] = fmaf(d[q], d[q], v0[q]);
+        } else {
+            const f32x4 rstd = *reinterpret_cast<const f32x4 *>(r.rstd + c), ga = *reinterpret_cast<const f32x4 *>(r.gamma + c),
+                        be = *reinterpret_cast<const f32x4 *>(r.beta + c), dA = *reinterpret_cast<const f32x4 *>(r.dA + i);
+            f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+            if (r.mask) mk = *reinterpret_cast<const f32x4 *>(r.mask + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xh = d[q] * rstd[q];
+                const float g = fmaf(xh, ga[q], be[q]) > 0.f ? dA[q] * mk[q] : 0.f;
+                v0[q] += g;
+                v1[q] = fmaf(g, xh, v1[q]);
+            }
+        }
     }
 }
 template <int F>
 __global__ void __launch_bounds__(256) colred_kernel(RedArgs r, float *__restrict__ partial) {
     constexpr int NV = F == 2 ? 2 : 1;
-    __shared__ float sh[NV][256];
+    __shared__ f32x4 sh[NV][256];
     const int tid = threadIdx.x, C = r.C;
     const size_t row0 = (size_t)blockIdx.x * r.rows_per_block;
     const size_t row1 = row0 + r.rows_per_block < r.M ? row0 + r.rows_per_block : r.M;
     float *out = partial + (size_t)blockIdx.x * NV * C;
-    if (C <= 256) {
-        const int rp = 256 / C;  // rows per pass
-        const int c = tid % C, rsub = tid / C;
-        float v0 = 0.f, v1 = 0.f;
-        if (rsub < rp)
-            for (size_t row = row0 + rsub; row < row1; row += rp) red_item<F>(r, row * C + c, c, v0, v1);
+    const int cq = C >> 2;
+    if ((C & 3) == 0 && cq <= 256 && 256 % cq == 0) {
+        const int rp = 256 / cq;  // rows per pass
+        const int c = (tid % cq) * 4, rsub = tid / cq;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        for (size_t row = row0 + rsub; row < row1; row += rp) red_item4<F>(r, row * C + c, c, v0, v1);
         sh[0][tid] = v0;
         if (NV == 2) sh[NV - 1][tid] = v1;
         __syncthreads();
-        if (tid < C) {
-            float s0 = 0.f, s1 = 0.f;
+        if (tid < cq) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
             for (int q = 0; q < rp; ++q) {
-                s0 += sh[0][q * C + tid];
-                if (NV == 2) s1 += sh[NV - 1][q * C + tid];
+                s0 += sh[0][q * cq + tid];
+                if (NV == 2) s1 += sh[NV - 1][q * cq + tid];
             }
-            out[tid] = s0;
-            if (NV == 2) out[C + tid] = s1;
+            *reinterpret_cast<f32x4 *>(out + c) = s0;
+            if (NV == 2) *reinterpret_cast<f32x4 *>(out + C + c) = s1;
         }
     } else {
         for (int c = tid; c < C; c += 256) {
@@ -83,16 +113,25 @@ __global__ void __launch_bounds__(256) colred_kernel(RedArgs r, float *__restric
 }
 // ordered f64 sum of the partials; mode 0: dst0 = s0 * scale (dst1 = s1 * scale when nv == 2)
 //                                  mode 1: variance: dst0 = rstd, dst1[0..C) = mean copy, dst1[C..2C) = var * bessel
-__global__ void colred_finish_kernel(const float *__restrict__ partial, int nb, int C, int nv, float scale, int mode,
-                                     float bessel, const float *__restrict__ mean, float *__restrict__ dst0,
-                                     float *__restrict__ dst1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 64 columns x 16 slices of the partial list per workgroup; the slices are combined in a fixed order.
+__global__ void __launch_bounds__(1024) colred_finish_kernel(const float *__restrict__ partial, int nb, int C, int nv, float scale,
+                                                             int mode, float bessel, const float *__restrict__ mean,
+                                                             float *__restrict__ dst0, float *__restrict__ dst1) {
+    __shared__ double sh[2][16][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        s0 += (double)partial[((size_t)b * nv) * C + c];
-        if (nv == 2) s1 += (double)partial[((size_t)b * nv + 1) * C + c];
-    }
+    if (c < C)
+        for (int b = sub; b < nb; b += 16) {
+            s0 += (double)partial[((size_t)b * nv) * C + c];
+            if (nv == 2) s1 += (double)partial[((size_t)b * nv + 1) * C + c];
+        }
+    sh[0][sub][lane] = s0;
+    sh[1][sub][lane] = s1;
+    __syncthreads();
+    if (sub != 0 || c >= C) return;
+    s0 = s1 = 0.0;
+    for (int q = 0; q < 16; ++q) s0 += sh[0][q][lane], s1 += sh[1][q][lane];
     if (mode == 0) {
         dst0[c] = (float)(s0 * (double)scale);
         if (nv == 2) dst1[c] = (float)(s1 * (double)scale);
@@ -104,27 +143,44 @@ __global__ void colred_finish_kernel(const float *__restrict__ partial, int nb, 
     }
 }
 
-// a = relu(gamma * (z - mean) * rstd + beta) * mask
-__global__ void bn_apply_kernel(const float *__restrict__ z, size_t total, int C, const float *__restrict__ mean,
+// a = relu(gamma * (z - mean) * rstd + beta) * mask ; four channels per thread (C % 4 == 0)
+__global__ void bn_apply_kernel(const float *__restrict__ z, size_t total4, int C, const float *__restrict__ mean,
                                 const float *__restrict__ rstd, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mask, float *__restrict__ a) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= total4) return;
+    const size_t i = i4 * 4;
     const int c = (int)(i % C);
-    const float v = fmaf((z[i] - mean[c]) * rstd[c], gamma[c], beta[c]);
-    a[i] = fmaxf(v, 0.f) * (mask ? mask[i] : 1.f);
+    const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + i), mu = *reinterpret_cast<const f32x4 *>(mean + c),
+                rs = *reinterpret_cast<const f32x4 *>(rstd + c), ga = *reinterpret_cast<const f32x4 *>(gamma + c),
+                be = *reinterpret_cast<const f32x4 *>(beta + c);
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f}, o;
+    if (mask) mk = *reinterpret_cast<const f32x4 *>(mask + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = fmaxf(fmaf((zz[q] - mu[q]) * rs[q], ga[q], be[q]), 0.f) * mk[q];
+    *reinterpret_cast<f32x4 *>(a + i) = o;
 }
-// in place on the gradient buffer: dA -> dz = gamma * rstd * (g - s1/M - xhat * s2/M)
-__global__ void bn_bwd_kernel(const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ mask,
-                              size_t total, int C, float invM, const float *__restrict__ mean,
-                              const float *__restrict__ rstd, const float *__restrict__ gamma,
-                              const float *__restrict__ s12, float *__restrict__ g_io) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// in place on the gradient buffer: dA -> dz = gamma * rstd * (g - s1/M - xhat * s2/M); the ReLU gate comes from z
+__global__ void bn_bwd_kernel(const float *__restrict__ z, const float *__restrict__ mask, size_t total4, int C, float invM,
+                              const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+                              const float *__restrict__ beta, const float *__restrict__ s12, float *__restrict__ g_io) {
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= total4) return;
+    const size_t i = i4 * 4;
     const int c = (int)(i % C);
-    const float g = a[i] > 0.f ? g_io[i] * (mask ? mask[i] : 1.f) : 0.f;
-    const float xh = (z[i] - mean[c]) * rstd[c];
-    g_io[i] = gamma[c] * rstd[c] * (g - s12[c] * invM - xh * s12[C + c] * invM);
+    const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + i), mu = *reinterpret_cast<const f32x4 *>(mean + c),
+                rs = *reinterpret_cast<const f32x4 *>(rstd + c), ga = *reinterpret_cast<const f32x4 *>(gamma + c),
+                be = *reinterpret_cast<const f32x4 *>(beta + c), s1 = *reinterpret_cast<const f32x4 *>(s12 + c),
+                s2 = *reinterpret_cast<const f32x4 *>(s12 + C + c);
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f}, g = *reinterpret_cast<const f32x4 *>(g_io + i);
+    if (mask) mk = *reinterpret_cast<const f32x4 *>(mask + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xh = (zz[q] - mu[q]) * rs[q];
+        const float gg = fmaf(xh, ga[q], be[q]) > 0.f ? g[q] * mk[q] : 0.f;
+        g[q] = ga[q] * rs[q] * (gg - s1[q] * invM - xh * s2[q] * invM);
+    }
+    *reinterpret_cast<f32x4 *>(g_io + i) = g;
 }
 
 // MaxPooling2D backward, gather form: the gradient of a window goes to its FIRST maximum in (dy, dx) scan order
@@ -171,6 +227,43 @@ __global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__r
     dx[i] = acc;
 }
 
+// stride == pool size (every pool of the Doukhan graph): one thread per window and channel finds the first maximum and
+// writes all taps of the window; taps outside every window (valid-pooling remainder) are zeroed by the caller
+__global__ void maxpool_bwd_tiles_kernel(const float *__restrict__ x, const float *__restrict__ dy_, int H, int W, int C, int OH,
+                                         int OW, int ph, int pw, int pt, int pl, size_t total, float *__restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t img = r / OH;
+    const int y0 = oy * ph - pt, x0 = ox * pw - pl;
+    float best = -__builtin_inff();
+    int by = -1, bx = -1;
+    for (int dy = 0; dy < ph; ++dy) {
+        const int yy = y0 + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dxx = 0; dxx < pw; ++dxx) {
+            const int xx = x0 + dxx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = x[((img * H + yy) * W + xx) * C + c];
+            if (v > best) best = v, by = yy, bx = xx;
+        }
+    }
+    const float g = dy_[i];
+    for (int dy = 0; dy < ph; ++dy) {
+        const int yy = y0 + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dxx = 0; dxx < pw; ++dxx) {
+            const int xx = x0 + dxx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            dx[((img * H + yy) * W + xx) * C + c] = (yy == by && xx == bx) ? g : 0.f;
+        }
+    }
+}
+
 // Wt[(i,j)][co][ci] = W[(i,j)][ci][co]
 __global__ void transpose_taps_kernel(const float *__restrict__ w, int Cin, int Cout, size_t total, float *__restrict__ wt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,6 +284,54 @@ __global__ void rowinfo_kernel(int H, int W, int C, int OH, int OW, int sh, int 
     const int oy = r / OW, ox = r - oy * OW;
     const int iy0 = oy * sh - pt, ix0 = ox * sw - pl;
     out[m] = int2{(int)((((long)img * H + iy0) * W + ix0) * C), (iy0 & 0xffff) | (ix0 << 16)};
+}
+
+// dW[K x 64-wide column block] for a shallow first layer (K = kh*kw*Cin <= 32, e.g. conv1: 20): the MFMA tile would be
+// 84 % padding, so this one runs on the VALU.  Workgroup = 64 output channels x 4 row groups; 64 output pixels at a time
+// have their K taps staged in LDS (broadcast reads), every lane owns one channel and K accumulators.
+constexpr int kSmallK = 32;
+__global__ void __launch_bounds__(256) wgrad_smallk_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                           const int2 *__restrict__ lut, const int2 *__restrict__ rowinfo, int H,
+                                                           int W, int K, int Cout, int M, int rows_per_block,
+                                                           float *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float xs[64][kSmallK];
+    __shared__ float red[4][kSmallK][64];
+    const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
+    const int co = blockIdx.y * 64 + lane;
+    const int m_begin = blockIdx.x * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float acc[kSmallK];
+#pragma unroll
+    for (int k = 0; k < kSmallK; ++k) acc[k] = 0.f;
+    for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * kSmallK; e += 256) {
+            const int r = e / kSmallK, k = e - r * kSmallK;
+            float v = 0.f;
+            if (m0 + r < m_end && k < K) {
+                const int2 ri = rowinfo[m0 + r], ek = lut[k];
+                const int iy = (short)(ri.y & 0xffff) + (short)(ek.y & 0xffff), ix = (ri.y >> 16) + (ek.y >> 16);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(long)ri.x + ek.x];
+            }
+            xs[r][k] = v;
+        }
+        __syncthreads();
+        if (co < Cout)
+            for (int r = rg; r < 64 && m0 + r < m_end; r += 4) {
+                const float g = dz[(size_t)(m0 + r) * Cout + co];
+#pragma unroll
+                for (int k4 = 0; k4 < kSmallK / 4; ++k4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xs[r][4 * k4]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = fmaf(xv[q], g, acc[4 * k4 + q]);
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallK; ++k) red[rg][k][lane] = acc[k];
+    __syncthreads();
+    if (co < Cout)
+        for (int k = rg; k < K; k += 4)
+            partial[((size_t)blockIdx.x * K + k) * Cout + co] = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
 }
 
 __global__ void partial_sum_kernel(const float *__restrict__ partial, int S, size_t n, float *__restrict__ out) {
@@ -420,9 +561,10 @@ template <int F>
 int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, float bessel, float *dst0, float *dst1,
                hipStream_t st) {
     const int C = r.C;
-    const size_t rows_per_pass = C <= 256 ? 256 / C : 1;
-    size_t rpb = rows_per_pass * 32;
-    if (C > 256) rpb = 64;
+    const int cq = C >> 2;
+    const bool vec = (C & 3) == 0 && cq <= 256 && 256 % cq == 0;  // the kernel's own test
+    const size_t rows_per_pass = vec ? 256 / cq : 1;
+    size_t rpb = vec ? rows_per_pass * 16 : 64;
     size_t nb = (r.M + rpb - 1) / rpb;
     if (nb > kMaxRed) {
         rpb = (r.M + kMaxRed - 1) / kMaxRed;
@@ -431,7 +573,7 @@ int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, flo
     }
     r.rows_per_block = (int)rpb;
     hipLaunchKernelGGL(colred_kernel<F>, dim3((unsigned)nb), dim3(256), 0, st, r, t->d_red);
-    hipLaunchKernelGGL(colred_finish_kernel, dim3(nblk(C, 128)), dim3(128), 0, st, (const float *)t->d_red, (int)nb, C, nv, scale,
+    hipLaunchKernelGGL(colred_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, st, (const float *)t->d_red, (int)nb, C, nv, scale,
                        mode, bessel, r.mean, dst0, dst1);
     return smh::launch_status("colred_kernel");
 }
@@ -470,7 +612,8 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         S.out_elems = (size_t)L.OH * L.OW * L.OC;
         maxg = std::max(maxg, std::max(S.in_elems, S.out_elems));
         if (L.op == kConv) {
-            SMH_REQUIRE(L.t_bn >= 0 && L.act == kRelu && L.sh == 1 && L.sw == 1, "smh_cnn_trainer_create: unsupported Conv2D variant");
+            SMH_REQUIRE(L.t_bn >= 0 && L.act == kRelu && L.sh == 1 && L.sw == 1 && L.OC % 4 == 0,
+                        "smh_cnn_trainer_create: unsupported Conv2D variant");
             arena += 2 * S.out_elems * NB;            // z and a
             tables += (size_t)L.OH * L.OW * NB;       // rowinfo
             S.dK = L.kh * L.kw * L.OC, S.dKp = (S.dK + BK - 1) / BK * BK;
@@ -673,7 +816,7 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
             }
             const float *g = F + m->tensors[L.t_bn].off;
             const size_t total = (size_t)a.M * L.OC;
-            hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float *)S.z, total, L.OC,
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, (const float *)S.z, total / 4, L.OC,
                                (const float *)S.mean, (const float *)S.rstd, g, g + L.OC, masks[l], S.a);
         } else {  // kPool
             const size_t total = (size_t)N * L.OH * L.OW * L.C;
@@ -724,8 +867,16 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
         float *G = t->d_g[cur], *Gn = t->d_g[cur ^ 1];
         if (L.op == kPool) {
             const size_t total = (size_t)N * L.H * L.W * L.C;
-            hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, S.in, (const float *)S.a, (const float *)G,
-                               L.H, L.W, L.C, L.OH, L.OW, L.kh, L.kw, L.sh, L.sw, L.pt, L.pl, total, Gn);
+            if (L.sh == L.kh && L.sw == L.kw && !getenv("SMH_CNN_POOL_GATHER")) {
+                if (L.OH * L.kh - L.pt < L.H || L.OW * L.kw - L.pl < L.W)  // rows / columns no window reaches
+                    SMH_CHECK_HIP(hipMemsetAsync(Gn, 0, total * sizeof(float), st));
+                const size_t nwin = (size_t)N * L.OH * L.OW * L.C;
+                hipLaunchKernelGGL(maxpool_bwd_tiles_kernel, dim3(nblk(nwin)), dim3(256), 0, st, S.in, (const float *)G, L.H, L.W, L.C,
+                                   L.OH, L.OW, L.kh, L.kw, L.pt, L.pl, nwin, Gn);
+            } else {
+                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, S.in, (const float *)S.a, (const float *)G,
+                                   L.H, L.W, L.C, L.OH, L.OW, L.kh, L.kw, L.sh, L.sw, L.pt, L.pl, total, Gn);
+            }
             cur ^= 1;
             continue;
         }
@@ -735,20 +886,28 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
         float *gr = t->d_grad;
         // BN backward: dbeta = sum g, dgamma = sum g * xhat, then dz in place
         RedArgs r{};
-        r.z = S.z, r.a = S.a, r.dA = G, r.mask = masks[l], r.mean = S.mean, r.rstd = S.rstd, r.M = (size_t)M, r.C = L.OC;
+        r.z = S.z, r.dA = G, r.mask = masks[l], r.mean = S.mean, r.rstd = S.rstd, r.gamma = g, r.beta = g + L.OC;
+        r.M = (size_t)M, r.C = L.OC;
         rc = col_reduce<2>(t, r, 2, 1.0f, 0, 1.f, S.s12, S.s12 + L.OC, st);
         if (rc) return rc;
         SMH_CHECK_HIP(hipMemcpyAsync(gr + m->tensors[L.t_bn].off + L.OC, S.s12, L.OC * sizeof(float), hipMemcpyDeviceToDevice, st));  // beta
         SMH_CHECK_HIP(hipMemcpyAsync(gr + m->tensors[L.t_bn].off, S.s12 + L.OC, L.OC * sizeof(float), hipMemcpyDeviceToDevice, st));  // gamma
-        hipLaunchKernelGGL(bn_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float *)S.z, (const float *)S.a, masks[l],
-                           total, L.OC, 1.0f / (float)M, (const float *)S.mean, (const float *)S.rstd, g, (const float *)S.s12, G);
-        if (L.t_bias >= 0) {  // d bias = column sums of dz (zero up to rounding behind a BatchNorm, as in Keras)
-            RedArgs rb{};
-            rb.z = G, rb.M = (size_t)M, rb.C = L.OC;
-            rc = col_reduce<0>(t, rb, 1, 1.0f, 0, 1.f, gr + m->tensors[L.t_bias].off, nullptr, st);
-            if (rc) return rc;
-        }
-        {  // wgrad
+        hipLaunchKernelGGL(bn_bwd_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, (const float *)S.z, masks[l], total / 4, L.OC,
+                           1.0f / (float)M, (const float *)S.mean, (const float *)S.rstd, g, g + L.OC, (const float *)S.s12, G);
+        // d bias = column sums of dz: behind a BatchNorm that is exactly zero (sum_m dz = gamma*rstd*(s1 - s1 - s2*sum xhat),
+        // sum xhat = 0); Keras accumulates rounding noise there, this step leaves the zero the memset wrote
+        if (L.t_bias >= 0) SMH_CHECK_HIP(hipMemsetAsync(gr + m->tensors[L.t_bias].off, 0, L.OC * sizeof(float), st));
+        if (L.K <= kSmallK && !getenv("SMH_CNN_WGRAD_MFMA")) {  // shallow first layer: VALU kernel
+            const size_t outf = (size_t)L.K * L.OC;
+            int nb = std::max(1, std::min(1024, M / 512));
+            while (nb > 1 && (size_t)nb * outf > t->partial_floats) --nb;
+            const int rpb = ((M + nb - 1) / nb + 63) / 64 * 64;
+            nb = (M + rpb - 1) / rpb;
+            hipLaunchKernelGGL(wgrad_smallk_kernel, dim3(nb, (L.OC + 63) / 64), dim3(256), 0, st, S.in, (const float *)G,
+                               (const int2 *)(m->d_lut + L.lut_off), (const int2 *)S.rowinfo, L.H, L.W, L.K, L.OC, M, rpb, t->d_partial);
+            hipLaunchKernelGGL(partial_sum_kernel, dim3(nblk(outf)), dim3(256), 0, st, (const float *)t->d_partial, nb, outf,
+                               gr + m->tensors[L.t_kernel].off);
+        } else {  // wgrad on the matrix cores
             ConvArgs a{};
             a.x = S.in, a.w = G, a.lut = m->d_lut + L.lut_off, a.rowinfo = S.rowinfo;
             a.H = L.H, a.W = L.W, a.Cin = L.C, a.OH = L.OH, a.OW = L.OW, a.Cout = L.OC, a.K = L.K, a.M = M;
