@@ -1,0 +1,101 @@
+"""End-to-end TRAINING throughput (BASELINE config 4's shape): per step and per GPU, `--batch` synthetic 1 s clips
+(music | speech | mixtures, labels cycling, SMR -5..20 dB) -> HIP front end (STFT -> HPSS 21x11 -> log-mel ->
+standardise -> W=68 patches, with the reference's Gaussian noise augmentation) -> B3_MTL training step (training forward,
+losses, backward, ONE all-reduce of the flat gradient over RCCL when WORLD_SIZE > 1, SGD with momentum and clipnorm).
+Launch like bench.py:  python tools/bench_train.py            (1 GPU)
+                       python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
+Prints one JSON line on rank 0.  Not the headline metric (bench.py is); documents the training path end to end."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step (a multiple of 3)")
+    ap.add_argument("--classes", type=int, default=3, choices=[3, 5])
+    args = ap.parse_args()
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from sm_hpss_mtl_amd.batching import make_labels_3class, make_labels_5class
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    from sm_hpss_mtl_amd.model import B3MTL
+    from sm_hpss_mtl_amd.synth import synth_clips
+
+    groups = 3 if args.classes == 3 else 5
+    bs = args.batch // groups
+    B = bs * groups
+    fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
+    model = B3MTL(n_feat=240, patch_size=68, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
+    audio = torch.from_numpy(np.tile(synth_clips(64, seed=2000 + rank), ((B + 63) // 64, 1))[:B]).cuda()
+    smr = np.array([(-5, 0, 5, 10, 15, 20)[i % 6] for i in range(bs)], np.float64)
+    lab = make_labels_3class(bs, smr) if args.classes == 3 else make_labels_5class(bs, smr, smr[::-1].copy())
+    y = model.pack_targets(lab)
+    assert y.shape[0] == B, (y.shape, B)
+    out = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        res = fe.run(audio, W=68, shift=68, out=out)
+        out.update(fv=res["fv"], patches=res["patches"])
+        x = res["patches"]
+        x = x + 1e-5 * torch.randn_like(x)  # noise_augmentation (Proposed_Work_Results.py:239-242)
+        if timed:
+            ev[1].record()
+        r = model.train_on_batch(x, y)  # includes the gradient all-reduce and the optimiser step
+        if timed:
+            ev[2].record()
+        return r
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    step(timed=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "clips/sec HPSS + B3_MTL training step (1s@16kHz)", "value": round(world * B * args.steps / dt, 1),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=68 patches -> B3_MTL(%d-class) "
+                                            "train step, SGD(momentum 0.9, clipnorm 1)" % (B, args.classes),
+                                            "gradient_allreduce_bytes": 4 * model.count_params() if world > 1 else 0},
+            "stages_ms": {"front_end_and_augmentation": round(ev[0].elapsed_time(ev[1]), 4),
+                          "train_step_incl_allreduce_and_host_sync": round(ev[1].elapsed_time(ev[2]), 4)},
+            "last_losses": dict(zip(model.metrics_names, [round(float(v), 5) for v in last]))}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
