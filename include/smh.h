@@ -266,8 +266,8 @@ int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, float *d_out,
                         size_t work_bytes, void *stream);
 
 /* ---- a13 / a14: training step of the Conv2D MTL baselines (what model.fit runs per batch for the models compiled at
- * lib/proposed_architectures.py:499-506 / :572-580 / :750-757).  Built for SMH_CNN_DOUKHAN; the other two kinds are
- * refused at creation.  The trainer owns its activations, gradients and optimiser state (sized for max_batch).
+ * lib/proposed_architectures.py:499-506 / :572-580 / :750-757), all three kinds.  The trainer owns its activations,
+ * gradients and optimiser state (sized for max_batch >= 2: BatchNorm needs a batch).
  *   d_x (N, H, W) images; d_y (N, out_dim) targets laid out like the forward output [S | M | (N) | R | 3C one-hot]
  *   d_drop: Dropout masks (0 or 1/(1-rate)) of the trunk, one (N, dim_i) block per Dropout layer in graph order
  *           (smh_cnn_trainer_num_dropouts / _dropout_info give dim_i and rate_i), or NULL (no dropout)

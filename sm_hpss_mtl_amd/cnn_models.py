@@ -7,7 +7,7 @@
 The layer graph, the parameter table (names, Keras shapes, order) and all arithmetic live in libsmh.so
 (csrc/smh_cnn.hip); this class only keeps the host copy of the weights, initialises them the way the reference's
 initialisers do, and moves tensors.  Training (`fit` / `train_on_batch` / `evaluate`, cnn_training.py over
-`smh_cnn_train_step_f32`) is built for the Doukhan model; the other two raise NotImplementedError there.
+`smh_cnn_train_step_f32`) is built for all three.
 """
 from __future__ import annotations
 

@@ -4,7 +4,7 @@ Optimisers as compiled by the reference: Doukhan Adam(1e-4) (lib/proposed_archit
 SGD(ExponentialDecay(1e-3, 700, 0.1)) (:572-574), Jang Adam(1e-3) (:750-751); Keras defaults beta_1 0.9, beta_2 0.999,
 epsilon 1e-7.  The step itself -- training-mode forward, losses, backward, update, BatchNorm moving averages -- runs
 in libsmh (smh_cnn_train.hip); torch supplies device memory, the random dropout masks and, for data-parallel
-training, ONE all-reduce of the flat gradient over RCCL.  Built for the Doukhan model.
+training, ONE all-reduce of the flat gradient over RCCL.
 """
 from __future__ import annotations
 
@@ -39,9 +39,6 @@ class CnnTrainingMixin(TrainingMixin):
         return self.initial_learning_rate
 
     def _get_trainer(self, n):
-        if self.kind != "Doukhan":
-            raise NotImplementedError("training is built for the Doukhan MTL model; %s MTL runs inference only "
-                                      "(load trained weights with set_weights)" % self.kind)
         if self._trainer is None or n > self._trainer_cap:
             if self._trainer is not None:
                 self.lib.smh_cnn_trainer_destroy(self._trainer)
@@ -56,6 +53,15 @@ class CnnTrainingMixin(TrainingMixin):
                 _lib.check(self.lib.smh_cnn_trainer_dropout_info(h, i, C.byref(dim), C.byref(rate)), "smh_cnn_trainer_dropout_info")
                 self._drop_spec.append((int(dim.value), float(rate.value)))
         return self._trainer
+
+    def _l2_penalty(self):
+        """0.01 * sum w^2 over the kernels that carry kernel_regularizer=l2(): the heads' Dense(16) kernels; for Jang every
+        mel-scale / Conv2D / Dense kernel and the '3C' kernel as well (proposed_architectures.py:630-747)."""
+        w = self.get_weights_dict()
+        names = [n + "/dense/kernel" for n in self.output_names[:-1]]
+        if self.kind == "Jang":
+            names += [k for k in w if k.endswith("/kernel") and (k.startswith(("conv", "fc", "3C")) or "_melCl" in k)]
+        return float(sum(0.01 * np.sum(w[k].astype(np.float64) ** 2) for k in names))
 
     def dropout_spec(self, n=2):
         """[(dim, rate)] of the trunk's Dropout layers in graph order."""

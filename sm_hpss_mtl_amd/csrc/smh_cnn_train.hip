@@ -12,8 +12,9 @@
 // partials, f64 finish), ReLU and Dropout ride in the normalisation kernel; their backward is one column reduction
 // plus one elementwise kernel, in place on the gradient buffer.  Max-pooling routes the gradient to the first maximum
 // of each window (gather form, no atomics).  The heads reuse heads_train_kernel of the B3_MTL trainer.
-// Built: Doukhan (all layer kinds it has).  Papakostas (LRN, stride-2 dgrad) and Jang (mel-scale layer, l2 on every
-// kernel) are refused with SMH_E_INVALID at trainer creation.
+// Papakostas adds LRN + ReLU backward (two passes), Conv2D without BatchNorm (gate + real bias gradients), a stride-2 data
+// gradient (dz zero-stuffed, then the stride-1 GEMM) and overlapping pooling; Jang adds the mel-scale layer's weight
+// gradient, a 3-channel data gradient (GEMM columns padded to 4), Dropout on feature maps and l2() on every kernel.
 #include <cstdlib>
 
 #include "smh_cnn_impl.h"
@@ -264,15 +265,88 @@ __global__ void maxpool_bwd_tiles_kernel(const float *__restrict__ x, const floa
     }
 }
 
-// Wt[(i,j)][co][ci] = W[(i,j)][ci][co]
-__global__ void transpose_taps_kernel(const float *__restrict__ w, int Cin, int Cout, size_t total, float *__restrict__ wt) {
+// ReLU behind a Conv2D without BatchNorm (Papakostas conv3): dz = a > 0 ? dA : 0, in place
+__global__ void relu_bwd_kernel(const float *__restrict__ a, size_t total, float *__restrict__ g_io) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total && !(a[i] > 0.f)) g_io[i] = 0.f;
+}
+// tf.nn.local_response_normalization + ReLU backward.  y = relu(v), v = x * u^-beta, u = 1 + alpha * sum_{|d-c|<=r} x_d^2:
+//   dx_c = dv_c * u_c^-beta - 2 alpha beta x_c * sum_{|d-c|<=r} dv_d x_d u_d^(-beta-1),   dv = y > 0 ? dy : 0.
+// Pass 1 (in place on the gradient): g <- dv * u^-beta, t <- dv * x * u^(-beta-1); pass 2 gathers the window of t.
+__global__ void lrn_bwd1_kernel(const float *__restrict__ x, const float *__restrict__ y, int C, int radius, float alpha,
+                                float beta, size_t total, float *__restrict__ g_io, float *__restrict__ t) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int ci = (int)(i % Cin);
-    const size_t r = i / Cin;
+    const int c = (int)(i % C);
+    const float *px = x + (i - c);
+    float s = 0.f;
+    for (int d = max(0, c - radius); d <= min(C - 1, c + radius); ++d) s = fmaf(px[d], px[d], s);
+    const float u = 1.f + alpha * s;
+    const float dv = y[i] > 0.f ? g_io[i] : 0.f;
+    const float ub = powf(u, -beta);
+    g_io[i] = dv * ub;
+    t[i] = dv * px[c] * ub / u;
+}
+__global__ void lrn_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ p, const float *__restrict__ t, int C,
+                                int radius, float alpha, float beta, size_t total, float *__restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const float *pt = t + (i - c);
+    float s = 0.f;
+    for (int d = max(0, c - radius); d <= min(C - 1, c + radius); ++d) s += pt[d];
+    dx[i] = p[i] - 2.f * alpha * beta * x[i] * s;
+}
+// strided Conv2D data gradient: dz (N, OH, OW, C) -> zero-stuffed (N, (OH-1)*sh+1, (OW-1)*sw+1, C), so that the
+// stride-1 data-gradient GEMM applies (the buffer is zeroed first)
+__global__ void stuff_kernel(const float *__restrict__ dz, int OH, int OW, int C, int sh, int sw, int SH, int SW, size_t total,
+                             float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t img = r / OH;
+    out[((img * SH + (size_t)oy * sh) * SW + (size_t)ox * sw) * C + c] = dz[i];
+}
+
+// Wt[(i,j)][co][ci] = W[(i,j)][ci][co]; rows of Wt are `ld` >= Cin wide (zero padded: the GEMM wants a multiple of 4)
+__global__ void transpose_taps_kernel(const float *__restrict__ w, int Cin, int Cout, int ld, size_t total,
+                                      float *__restrict__ wt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i % ld);
+    const size_t r = i / ld;
     const int co = (int)(r % Cout);
     const size_t ij = r / Cout;
-    wt[i] = w[(ij * Cin + ci) * Cout + co];
+    wt[i] = ci < Cin ? w[(ij * Cin + ci) * Cout + co] : 0.f;
+}
+// Jang's mel-scale layer (melcl_kernel of smh_cnn_impl.h), weight gradient: y = tanh(sum_{b,d} x[top+b][t+d-half] w[b][d][ch])
+// one workgroup per filter row, one thread per weight (b, d, ch), the batch and the frames summed in order.
+// dA has `ldc` floats per pixel (the data gradient of the next Conv2D is written with a padded channel count).
+__global__ void __launch_bounds__(256) melcl_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ dA, const MelCl *__restrict__ f, int N, int rows_in,
+                                                        int W, int rows_out, int tdim, int ldc, float *__restrict__ grad) {
+    const int r = blockIdx.x;
+    const MelCl e = f[r];
+    const int half = tdim / 2;
+    for (int q = threadIdx.x; q < e.width * tdim * 3; q += blockDim.x) {
+        const int ch = q % 3, bd = q / 3, d = bd % tdim, b = bd / tdim;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float *xr = x + ((size_t)n * rows_in + e.top + b) * W;
+            const size_t o = ((size_t)n * rows_out + r) * W;
+            for (int t = 0; t < W; ++t) {
+                const int tt = t + d - half;
+                if ((unsigned)tt >= (unsigned)W) continue;
+                const float yv = y[(o + t) * 3 + ch];
+                acc = fmaf(xr[tt], dA[(o + t) * ldc + ch] * (1.f - yv * yv), acc);
+            }
+        }
+        grad[e.woff + q] = acc;
+    }
 }
 
 __global__ void rowinfo_kernel(int H, int W, int C, int OH, int OW, int sh, int sw, int pt, int pl, size_t total,
@@ -507,6 +581,7 @@ struct LayerState {
     size_t in_elems = 0, out_elems = 0;  // per image
     int2 *rowinfo = nullptr, *dlut = nullptr;
     int dK = 0, dKp = 0;          // dgrad GEMM depth kh*kw*Cout (padded)
+    int SH = 0, SW = 0;           // height / width of dz as the data-gradient GEMM sees it (zero-stuffed when strided)
     float *mean = nullptr, *rstd = nullptr, *s12 = nullptr;  // per channel
     unsigned bstat_off = 0;       // [mean | var] of this layer's BN in the batch-statistics buffer
     size_t drop_off = 0;          // offset (in units of one image's floats) of this layer's mask block
@@ -523,7 +598,7 @@ struct smh_cnn_trainer {
     size_t drop_per_image = 0;  // floats of dropout mask per image, all layers
     int n_drop = 0;
     float *d_arena = nullptr, *d_g[2] = {nullptr, nullptr}, *d_partial = nullptr, *d_red = nullptr, *d_wt = nullptr;
-    float *d_chan = nullptr, *d_ones = nullptr, *d_zeros = nullptr;
+    float *d_chan = nullptr, *d_ones = nullptr, *d_zeros = nullptr, *d_tmp = nullptr;
     float *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr, *d_scratch = nullptr;
     float *d_grad = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_bstat = nullptr;
     int2 *d_tables = nullptr;
@@ -582,7 +657,7 @@ int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, flo
 
 extern "C" void smh_cnn_trainer_destroy(smh_cnn_trainer *t) {
     if (!t) return;
-    for (float *p : {t->d_arena, t->d_g[0], t->d_g[1], t->d_partial, t->d_red, t->d_wt, t->d_chan, t->d_ones, t->d_zeros, t->d_pre,
+    for (float *p : {t->d_arena, t->d_g[0], t->d_g[1], t->d_partial, t->d_red, t->d_wt, t->d_chan, t->d_ones, t->d_zeros, t->d_tmp, t->d_pre,
                      t->d_dpre, t->d_dxh, t->d_scratch, t->d_grad, t->d_s1, t->d_s2, t->d_bstat})
         (void)hipFree(p);
     (void)hipFree(t->d_tables);
@@ -593,16 +668,15 @@ extern "C" void smh_cnn_trainer_destroy(smh_cnn_trainer *t) {
 
 extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer **out) {
     SMH_REQUIRE(m && out && max_batch >= 2, "smh_cnn_trainer_create: bad argument (a training batch needs at least 2 samples)");
-    SMH_REQUIRE(m->cfg.kind == SMH_CNN_DOUKHAN,
-                "smh_cnn_trainer_create: training is built for the Doukhan MTL model only (Papakostas: LRN and stride-2 "
-                "data gradients, Jang: mel-scale layer gradients are not built)");
+    SMH_REQUIRE(m->cfg.kind == SMH_CNN_DOUKHAN || m->cfg.kind == SMH_CNN_PAPAKOSTAS || m->cfg.kind == SMH_CNN_JANG,
+                "smh_cnn_trainer_create: unknown model kind");
     smh_cnn_trainer *t = new smh_cnn_trainer();
     t->m = m, t->max_batch = max_batch;
     const size_t NB = (size_t)max_batch;
     const int nl = (int)m->layers.size();
     t->ls.resize(nl);
     // sizes
-    size_t arena = 0, tables = 0, chan = 0, maxg = (size_t)m->cfg.in_h * m->cfg.in_w, wt = 0, maxC = 64;
+    size_t arena = 0, tables = 0, chan = 0, maxg = (size_t)m->cfg.in_h * m->cfg.in_w, wt = 0, maxC = 64, tmp = 0;
     unsigned bstat = 0;
     size_t in_elems = (size_t)m->cfg.in_h * m->cfg.in_w;
     for (int l = 0; l < nl; ++l) {
@@ -612,18 +686,26 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         S.out_elems = (size_t)L.OH * L.OW * L.OC;
         maxg = std::max(maxg, std::max(S.in_elems, S.out_elems));
         if (L.op == kConv) {
-            SMH_REQUIRE(L.t_bn >= 0 && L.act == kRelu && L.sh == 1 && L.sw == 1 && L.OC % 4 == 0,
+            SMH_REQUIRE(L.OC % 4 == 0 && (L.t_bn < 0 || L.act == kRelu) && (L.act == kRelu || L.act == kNone) &&
+                            ((L.sh == 1 && L.sw == 1) || (L.pt == 0 && L.pl == 0)),
                         "smh_cnn_trainer_create: unsupported Conv2D variant");
-            arena += 2 * S.out_elems * NB;            // z and a
+            arena += (L.t_bn >= 0 ? 2 : 1) * S.out_elems * NB;  // z (in front of a BatchNorm) and a
+            S.SH = (L.OH - 1) * L.sh + 1, S.SW = (L.OW - 1) * L.sw + 1;
+            if (l > 0 && (L.sh > 1 || L.sw > 1)) tmp = std::max(tmp, (size_t)S.SH * S.SW * L.OC * NB);
             tables += (size_t)L.OH * L.OW * NB;       // rowinfo
             S.dK = L.kh * L.kw * L.OC, S.dKp = (S.dK + BK - 1) / BK * BK;
-            if (l > 0) tables += S.dKp, wt = std::max(wt, (size_t)L.K * L.OC);
+            const size_t ldc = ((size_t)L.C + 3) & ~(size_t)3;  // the data gradient is written with a padded channel count
+            if (l > 0) tables += S.dKp, wt = std::max(wt, (size_t)L.kh * L.kw * L.OC * ldc), maxg = std::max(maxg, (size_t)L.H * L.W * ldc);
             chan += 4 * (size_t)L.OC;                 // mean, rstd, s1|s2
             S.bstat_off = bstat, bstat += 2 * L.OC;
             maxC = std::max(maxC, (size_t)L.OC);
             if (L.drop > 0.f) S.drop_off = t->drop_per_image, t->drop_per_image += S.out_elems, t->n_drop++;
-            SMH_REQUIRE(l == 0 || L.C % 4 == 0, "smh_cnn_trainer_create: Cin=%d is not a multiple of 4", L.C);
         } else if (L.op == kPool) {
+            arena += S.out_elems * NB;
+        } else if (L.op == kLrnRelu) {
+            arena += S.out_elems * NB;
+            tmp = std::max(tmp, S.out_elems * NB);
+        } else if (L.op == kMelCl && l == 0) {
             arena += S.out_elems * NB;
         } else {
             delete t;
@@ -648,6 +730,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
     alloc(&t->d_partial, t->partial_floats);
     alloc(&t->d_red, (size_t)kMaxRed * 2 * maxC);
     alloc(&t->d_wt, wt);
+    alloc(&t->d_tmp, tmp);
     alloc(&t->d_chan, chan);
     size_t maxN = maxC;  // widest GEMM output: the data gradient of a layer has its INPUT width
     for (const Layer &L : m->layers)
@@ -680,7 +763,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         const Layer &L = m->layers[l];
         LayerState &S = t->ls[l];
         if (L.op == kConv) {
-            S.z = ap, ap += S.out_elems * NB;
+            if (L.t_bn >= 0) S.z = ap, ap += S.out_elems * NB;
             S.a = ap, ap += S.out_elems * NB;
             S.rowinfo = tp, tp += (size_t)L.OH * L.OW * NB;
             const size_t total = (size_t)L.OH * L.OW * NB;
@@ -691,7 +774,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
                 for (int k = 0; k < S.dKp; ++k) {
                     if (k < S.dK) {
                         const int co = k % L.OC, ij = k / L.OC, j = ij % L.kw, i = ij / L.kw;
-                        dl[k] = int2{(-i * L.OW - j) * L.OC + co, ((-i) & 0xffff) | ((-j) << 16)};
+                        dl[k] = int2{(-i * S.SW - j) * L.OC + co, ((-i) & 0xffff) | ((-j) << 16)};
                     } else {
                         dl[k] = int2{0, 0x7fff | (0x7fff << 16)};
                     }
@@ -703,13 +786,18 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
             S.mean = cp, S.rstd = cp + L.OC, S.s12 = cp + 2 * L.OC, cp += 4 * (size_t)L.OC;
             add_seg(m->tensors[L.t_kernel].off, m->tensors[L.t_kernel].count, L.l2 ? 1 : 0, 0);
             if (L.t_bias >= 0) add_seg(m->tensors[L.t_bias].off, L.OC, 0, 0);
-            const size_t g = m->tensors[L.t_bn].off;
-            add_seg(g, 2 * (size_t)L.OC, 0, 0);  // gamma, beta
-            add_seg(g + 2 * (size_t)L.OC, L.OC, 2, S.bstat_off);
-            add_seg(g + 3 * (size_t)L.OC, L.OC, 3, S.bstat_off + L.OC);
-            folds.push_back(FoldEnt{(unsigned)L.es_off, (unsigned)L.OC, L.t_bias >= 0 ? (long)m->tensors[L.t_bias].off : -1, (long)g});
+            long g = -1;
+            if (L.t_bn >= 0) {
+                g = (long)m->tensors[L.t_bn].off;
+                add_seg(g, 2 * (size_t)L.OC, 0, 0);  // gamma, beta
+                add_seg(g + 2 * (size_t)L.OC, L.OC, 2, S.bstat_off);
+                add_seg(g + 3 * (size_t)L.OC, L.OC, 3, S.bstat_off + L.OC);
+            }
+            folds.push_back(FoldEnt{(unsigned)L.es_off, (unsigned)L.OC, L.t_bias >= 0 ? (long)m->tensors[L.t_bias].off : -1, g});
         } else {
             S.a = ap, ap += S.out_elems * NB;
+            if (L.op == kMelCl)  // 2 * n_mels trainable kernels, each with kernel_regularizer=l2() (:630, :639)
+                for (int q = 0; q < m->mel_rows; ++q) add_seg(m->tensors[q].off, m->tensors[q].count, 1, 0);
         }
     }
     if (e == hipSuccess) {
@@ -784,10 +872,12 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
             ConvArgs a{};
             a.x = src, a.w = F + m->tensors[L.t_kernel].off;
             a.es = t->d_ones, a.eb = L.t_bias >= 0 ? F + m->tensors[L.t_bias].off : t->d_zeros;
-            a.y = S.z, a.partial = t->d_partial, a.lut = m->d_lut + L.lut_off;
+            const bool bn_layer = L.t_bn >= 0;
+            float *gemm_out = bn_layer ? S.z : S.a;  // without a BatchNorm the activation rides in the GEMM epilogue
+            a.y = gemm_out, a.partial = t->d_partial, a.lut = m->d_lut + L.lut_off;
             a.H = L.H, a.W = L.W, a.Cin = L.C, a.OH = L.OH, a.OW = L.OW, a.Cout = L.OC, a.K = L.K;
             a.M = N * L.OH * L.OW;
-            a.sh = L.sh, a.sw = L.sw, a.pt = L.pt, a.pl = L.pl, a.act = kNone;
+            a.sh = L.sh, a.sw = L.sw, a.pt = L.pt, a.pl = L.pl, a.act = bn_layer ? kNone : L.act;
             a.ksteps = L.Kp / BK;
             a.vec4 = (L.C % 4 == 0) ? 1 : 0;
             const int bn = L.OC <= 64 ? 64 : 128;
@@ -799,7 +889,11 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
             if (a.ksplit > 1) {
                 const size_t MN = (size_t)a.M * L.OC;
                 hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nblk(MN)), dim3(256), 0, st, (const float *)t->d_partial, a.ksplit,
-                                   MN, L.OC, a.es, a.eb, (int)kNone, S.z);
+                                   MN, L.OC, a.es, a.eb, a.act, gemm_out);
+            }
+            if (!bn_layer) {
+                src = S.a;
+                continue;
             }
             // batch statistics: mean, then centred second moment
             RedArgs r{};
@@ -818,6 +912,13 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
             const size_t total = (size_t)a.M * L.OC;
             hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(total / 4)), dim3(256), 0, st, (const float *)S.z, total / 4, L.OC,
                                (const float *)S.mean, (const float *)S.rstd, g, g + L.OC, masks[l], S.a);
+        } else if (L.op == kLrnRelu) {
+            const size_t total = (size_t)N * L.H * L.W * L.C;
+            hipLaunchKernelGGL(lrn_relu_kernel, dim3(nblk(total)), dim3(256), 0, st, src, L.C, 5, 1e-4f, 0.75f, total, S.a);
+        } else if (L.op == kMelCl) {
+            const size_t total = (size_t)N * L.OH * L.OW;
+            hipLaunchKernelGGL(melcl_kernel, dim3(nblk(total)), dim3(256), 0, st, src, (const MelCl *)m->d_mel, F, L.H, L.W, L.OH,
+                               L.kw, total, S.a);
         } else {  // kPool
             const size_t total = (size_t)N * L.OH * L.OW * L.C;
             hipLaunchKernelGGL(maxpool_kernel, dim3(nblk(total)), dim3(256), 0, st, src, L.H, L.W, L.C, L.OH, L.OW, L.kh, L.kw,
@@ -880,10 +981,33 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
             cur ^= 1;
             continue;
         }
+        if (L.op == kMelCl) {  // first layer: weight gradients only; G holds dA with 4 floats per pixel (3 channels + pad)
+            hipLaunchKernelGGL(melcl_bwd_kernel, dim3(L.OH), dim3(256), 0, st, S.in, (const float *)S.a, (const float *)G,
+                               (const MelCl *)m->d_mel, N, L.H, L.W, L.OH, L.kw, 4, t->d_grad);
+            continue;
+        }
+        if (L.op == kLrnRelu) {
+            const size_t total = (size_t)N * L.H * L.W * L.C;
+            hipLaunchKernelGGL(lrn_bwd1_kernel, dim3(nblk(total)), dim3(256), 0, st, S.in, (const float *)S.a, L.C, 5, 1e-4f, 0.75f,
+                               total, G, t->d_tmp);
+            hipLaunchKernelGGL(lrn_bwd2_kernel, dim3(nblk(total)), dim3(256), 0, st, S.in, (const float *)G, (const float *)t->d_tmp,
+                               L.C, 5, 1e-4f, 0.75f, total, Gn);
+            cur ^= 1;
+            continue;
+        }
         const int M = N * L.OH * L.OW;
         const size_t total = (size_t)M * L.OC;
-        const float *g = F + m->tensors[L.t_bn].off;
         float *gr = t->d_grad;
+        if (L.t_bn < 0) {  // bias + optional ReLU in the GEMM epilogue: gate, then the bias gradient is a plain column sum
+            if (L.act == kRelu) hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float *)S.a, total, G);
+            if (L.t_bias >= 0) {
+                RedArgs rb{};
+                rb.z = G, rb.M = (size_t)M, rb.C = L.OC;
+                rc = col_reduce<0>(t, rb, 1, 1.0f, 0, 1.f, gr + m->tensors[L.t_bias].off, nullptr, st);
+                if (rc) return rc;
+            }
+        } else {
+        const float *g = F + m->tensors[L.t_bn].off;
         // BN backward: dbeta = sum g, dgamma = sum g * xhat, then dz in place
         RedArgs r{};
         r.z = S.z, r.dA = G, r.mask = masks[l], r.mean = S.mean, r.rstd = S.rstd, r.gamma = g, r.beta = g + L.OC;
@@ -897,6 +1021,7 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
         // d bias = column sums of dz: behind a BatchNorm that is exactly zero (sum_m dz = gamma*rstd*(s1 - s1 - s2*sum xhat),
         // sum xhat = 0); Keras accumulates rounding noise there, this step leaves the zero the memset wrote
         if (L.t_bias >= 0) SMH_CHECK_HIP(hipMemsetAsync(gr + m->tensors[L.t_bias].off, 0, L.OC * sizeof(float), st));
+        }
         if (L.K <= kSmallK && !getenv("SMH_CNN_WGRAD_MFMA")) {  // shallow first layer: VALU kernel
             const size_t outf = (size_t)L.K * L.OC;
             int nb = std::max(1, std::min(1024, M / 512));
@@ -926,27 +1051,36 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
                                    a.y);
         }
         if (l > 0) {  // dgrad: dZ is the image, mirrored taps, kernel transposed per tap
-            const size_t wn = (size_t)L.K * L.OC;
-            hipLaunchKernelGGL(transpose_taps_kernel, dim3(nblk(wn)), dim3(256), 0, st, F + m->tensors[L.t_kernel].off, L.C, L.OC, wn,
-                               t->d_wt);
+            const int ldc = (L.C + 3) & ~3;  // columns of the data-gradient GEMM: Cin padded to a multiple of 4 (Jang conv1: 3 -> 4)
+            const size_t wn = (size_t)L.kh * L.kw * L.OC * ldc;
+            hipLaunchKernelGGL(transpose_taps_kernel, dim3(nblk(wn)), dim3(256), 0, st, F + m->tensors[L.t_kernel].off, L.C, L.OC, ldc,
+                               wn, t->d_wt);
+            const float *dzimg = G;
+            if (L.sh > 1 || L.sw > 1) {  // strided layer: zero-stuff dz, then it is a stride-1 data gradient
+                const size_t sn = (size_t)N * S.SH * S.SW * L.OC;
+                SMH_CHECK_HIP(hipMemsetAsync(t->d_tmp, 0, sn * sizeof(float), st));
+                hipLaunchKernelGGL(stuff_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float *)G, L.OH, L.OW, L.OC, L.sh, L.sw,
+                                   S.SH, S.SW, total, t->d_tmp);
+                dzimg = t->d_tmp;
+            }
             ConvArgs a{};
-            a.x = G, a.w = t->d_wt, a.es = t->d_ones, a.eb = t->d_zeros, a.y = Gn, a.partial = t->d_partial, a.lut = S.dlut;
-            a.H = L.OH, a.W = L.OW, a.Cin = L.OC, a.OH = L.H, a.OW = L.W, a.Cout = L.C, a.K = S.dK;
+            a.x = dzimg, a.w = t->d_wt, a.es = t->d_ones, a.eb = t->d_zeros, a.y = Gn, a.partial = t->d_partial, a.lut = S.dlut;
+            a.H = S.SH, a.W = S.SW, a.Cin = L.OC, a.OH = L.H, a.OW = L.W, a.Cout = ldc, a.K = S.dK;
             a.M = N * L.H * L.W;
             a.sh = a.sw = 1, a.pt = -L.pt, a.pl = -L.pl, a.act = kNone;
             a.ksteps = S.dKp / BK;
             a.vec4 = (L.OC % 4 == 0) ? 1 : 0;
-            const int bn = L.C <= 64 ? 64 : 128;
-            const int mt = (a.M + BM - 1) / BM, nt = (L.C + bn - 1) / bn;
+            const int bn = ldc <= 64 ? 64 : 128;
+            const int mt = (a.M + BM - 1) / BM, nt = (ldc + bn - 1) / bn;
             a.ksplit = choose_split(mt, nt, a.ksteps);
             if (const char *e = getenv("SMH_CNN_DSPLIT")) a.ksplit = std::max(1, std::min(atoi(e), a.ksteps));
-            while (a.ksplit > 1 && (size_t)a.ksplit * a.M * L.C > t->partial_floats) --a.ksplit;
+            while (a.ksplit > 1 && (size_t)a.ksplit * a.M * ldc > t->partial_floats) --a.ksplit;
             a.ksteps_per = (a.ksteps + a.ksplit - 1) / a.ksplit;
             launch_gemm<0>(a, a.M, bn, st);
             if (a.ksplit > 1) {
-                const size_t MN = (size_t)a.M * L.C;
+                const size_t MN = (size_t)a.M * ldc;
                 hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nblk(MN)), dim3(256), 0, st, (const float *)t->d_partial, a.ksplit,
-                                   MN, L.C, a.es, a.eb, (int)kNone, Gn);
+                                   MN, ldc, a.es, a.eb, (int)kNone, Gn);
             }
             cur ^= 1;
         }

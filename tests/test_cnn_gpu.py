@@ -81,8 +81,7 @@ def test_reference_constructors_and_initialisers():
     P["Model"] = "Jang_et_al_MTL"
     jang, lr = pa.get_Jang_MTL_model(P)
     assert lr == 0.001
-    with pytest.raises(NotImplementedError):  # training is built for the Doukhan model only
-        jang.train_on_batch(np.zeros((2, 514, 20), np.float32), [np.zeros((2, 1)), np.zeros((2, 1)), np.zeros((2, 2)), np.eye(3)[:2]])
+    assert jang.optimizer == "adam" and jang.learning_rate() == 0.001
     ref = oc.init_jang(0, 20, mel_init=True, randomize=False)
     for i in (0, 57, 119):  # Constant(mel weights) initialiser of the mel-scale kernels
         assert np.allclose(jang.weights["harm_melCl%d/kernel" % i], ref["harm_melCl%d/kernel" % i], rtol=1e-6, atol=1e-9)

@@ -118,7 +118,124 @@ def test_adam_update_and_moving_statistics():
         np.testing.assert_allclose(o, r, atol=2e-4)
 
 
-def test_fit_reduces_the_loss_and_other_kinds_refuse():
+def _papakostas(H, W, fc, seed=4):
+    from oracle import cnn_mtl
+    from sm_hpss_mtl_amd.cnn_models import CnnMTL
+    w = cnn_mtl.init_papakostas(seed=seed, H=H, W=W, fc=fc)
+    m = CnnMTL("Papakostas", (H, W, 1), seed=0, fc_width=fc)
+    m.set_weights_dict(w)
+    return m, w
+
+
+@pytest.mark.parametrize("H,W,N,fc,dropout", [(61, 68, 6, 64, False), (75, 41, 5, 128, True), (402, 68, 4, 256, True)])
+def test_papakostas_train_step_matches_autograd(H, W, N, fc, dropout):
+    """LRN + ReLU backward, stride-2 data gradient (zero-stuffed dz), overlapping 3x3/2 'same' pooling, Conv2D without
+    BatchNorm (real bias gradients), 'same' convolution."""
+    from oracle import cnn_mtl_train
+    m, w = _papakostas(H, W, fc)
+    x, y = _batch(N, H, W, 2)
+    drop = dh = odrop = odh = None
+    if dropout:
+        rng = np.random.default_rng(3)
+        spec = m.dropout_spec(N)
+        assert spec == [(fc, 0.5), (fc, 0.5)]
+        drop = [((rng.uniform(size=(N, d)) < 1 - r) / (1 - r)).astype(np.float32) for d, r in spec]
+        dh = ((rng.uniform(size=(N, 3, 16)) < 0.6) / 0.6).astype(np.float32)
+        odrop, odh = drop, {n: dh[:, i] for i, n in enumerate(("S", "M", "R"))}
+    ref = cnn_mtl_train.forward_backward(x, y, w, drop=odrop, drop_heads=odh, kind="Papakostas")
+    ref32 = cnn_mtl_train.forward_backward(x, y, w, drop=odrop, drop_heads=odh, kind="Papakostas", dtype=np.float32)["grads"]
+    res = dict(zip(m.metrics_names, m.train_on_batch(x, y, drop=drop, drop_heads=dh, apply=False)))
+    for k in ("S", "M", "R", "3C"):
+        assert res[k + "_loss"] == pytest.approx(ref["losses"][k], rel=2e-4, abs=2e-5), k
+    got = m.gradients()
+    bad = []
+    for name, g in ref["grads"].items():
+        scale = max(np.abs(g).max(), 1e-12)
+        err = np.abs(got[name].astype(np.float64) - g).max()
+        floor = np.abs(ref32[name].astype(np.float64) - g).max()
+        if name.endswith("dense/bias") or name in ("fc1/bias", "fc2/bias"):  # in front of a BatchNorm: analytic zero
+            continue
+        print("%-22s err/max %.2e   f32-oracle floor %.2e" % (name, err / scale, floor / scale))
+        if H < 100:
+            if not err / scale < 1e-3 + 4 * floor / scale:
+                bad.append("%s: %.3e vs %.3e" % (name, err, scale))
+        else:  # full-size image: a few pooling arg-maxima may flip (see _check_grads)
+            a, b = got[name].astype(np.float64).ravel(), g.ravel()
+            cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+            if not (cos > 0.9995 and err / scale < 0.1):
+                bad.append("%s: cosine %.6f err %.3e vs %.3e" % (name, cos, err, scale))
+    assert not bad, "\n".join(bad)
+
+
+def test_papakostas_sgd_update():
+    from oracle import cnn_mtl_train
+    H, W, N, fc = 61, 68, 6, 64
+    m, w = _papakostas(H, W, fc)
+    assert m.optimizer == "sgd" and m.learning_rate(700) == pytest.approx(1e-4)
+    x, y = _batch(N, H, W, 8)
+    ref = cnn_mtl_train.forward_backward(x, y, w, kind="Papakostas")
+    m.train_on_batch(x, y, drop=None, drop_heads=None, apply=False)
+    g = {k: v.astype(np.float64) for k, v in m.gradients().items()}
+    m.apply_gradients()
+    nw = cnn_mtl_train.sgd_step({k: v.astype(np.float64) for k, v in w.items()}, g, ref["bn_batch"], 1e-3)
+    got = m.get_weights_dict()
+    for k, v in nw.items():
+        tol = 2e-4 * max(1.0, np.abs(v).max()) if k.endswith(("moving_mean", "moving_variance")) else 3e-7 + 1e-6 * np.abs(v).max()
+        assert np.abs(got[k].astype(np.float64) - v).max() <= tol, k
+
+
+@pytest.mark.parametrize("W,N,dropout", [(12, 4, False), (20, 3, True), (68, 3, True)])
+def test_jang_train_step_matches_autograd(W, N, dropout):
+    """Mel-scale layer weight gradients, 3-channel data gradient (padded GEMM columns), Dropout on feature maps in front
+    of the pooling, l2() on every kernel, then one Adam step against the oracle fed with the device gradients."""
+    from oracle import cnn_mtl, cnn_mtl_train
+    from sm_hpss_mtl_amd.cnn_models import CnnMTL
+    w = cnn_mtl.init_jang(seed=2, W=W, mel_init=False)
+    m = CnnMTL("Jang", (514, W, 1), seed=0)
+    m.set_weights_dict(w)
+    x, y = _batch(N, 514, W, 6)
+    drop = dh = odh = None
+    if dropout:
+        rng = np.random.default_rng(5)
+        spec = m.dropout_spec(N)
+        assert [r for _, r in spec] == pytest.approx([0.4] * 5) and [d for d, _ in spec][3:] == [2048, 1024]
+        assert spec[0][0] == 240 * W * 32
+        drop = [((rng.uniform(size=(N, d)) < 1 - r) / (1 - r)).astype(np.float32) for d, r in spec]
+        dh = ((rng.uniform(size=(N, 3, 16)) < 0.6) / 0.6).astype(np.float32)
+        odh = {n: dh[:, i] for i, n in enumerate(("S", "M", "R"))}
+    ref = cnn_mtl_train.forward_backward(x, y, w, drop=drop, drop_heads=odh, kind="Jang")
+    ref32 = cnn_mtl_train.forward_backward(x, y, w, drop=drop, drop_heads=odh, kind="Jang", dtype=np.float32)["grads"]
+    res = dict(zip(m.metrics_names, m.train_on_batch(x, y, drop=drop, drop_heads=dh, apply=False)))
+    for k in ("S", "M", "R", "3C"):
+        assert res[k + "_loss"] == pytest.approx(ref["losses"][k], rel=2e-4, abs=2e-5), k
+    assert res["loss"] == pytest.approx(ref["loss"] + ref["l2"], rel=2e-4)
+    got = m.gradients()
+    bad, mel_err = [], 0.0
+    for name, g in ref["grads"].items():
+        if name.endswith("/bias") and not name.endswith("out/bias") and name != "3C/bias":
+            continue  # in front of a BatchNorm: analytic zero
+        scale = max(np.abs(g).max(), 1e-12)
+        err = np.abs(got[name].astype(np.float64) - g).max()
+        floor = np.abs(ref32[name].astype(np.float64) - g).max()
+        if "_melCl" in name:
+            mel_err = max(mel_err, err / scale)
+        else:
+            print("%-22s err/max %.2e   f32-oracle floor %.2e" % (name, err / scale, floor / scale))
+        if not err / scale < 2e-3 + 4 * floor / scale:
+            bad.append("%s: %.3e (floor %.3e) vs %.3e" % (name, err, floor, scale))
+    print("mel-scale kernels: worst err/max %.2e" % mel_err)
+    assert not bad, "\n".join(bad[:20])
+    g64 = {k: v.astype(np.float64) for k, v in got.items()}
+    m.apply_gradients()
+    nw, _, _ = cnn_mtl_train.adam_step({k: v.astype(np.float64) for k, v in w.items()}, g64, {}, {}, ref["bn_batch"], 1, lr=1e-3,
+                                       kind="Jang")
+    new = m.get_weights_dict()
+    for k, v in nw.items():
+        tol = 2e-4 * max(1.0, np.abs(v).max()) if k.endswith(("moving_mean", "moving_variance")) else 3e-7 + 2e-6 * np.abs(v).max()
+        assert np.abs(new[k].astype(np.float64) - v).max() <= tol, k
+
+
+def test_fit_reduces_the_loss():
     from sm_hpss_mtl_amd.cnn_models import CnnMTL
     H, W, N = 30, 68, 12
     m, _ = _model(H, W, seed=11)
@@ -130,8 +247,5 @@ def test_fit_reduces_the_loss_and_other_kinds_refuse():
     data = np.sum([hist.history[k + "_loss"] for k in ("S", "M", "R", "3C")], axis=0)  # without the l2 penalty
     assert data[-1] < 0.7 * data[0], data
     assert m.evaluate(x, yl)[0] < first[0]
-    p = CnnMTL("Papakostas", (60, 68, 1), seed=0, fc_width=64)
-    with pytest.raises(NotImplementedError):
-        p.train_on_batch(np.zeros((2, 60, 68), np.float32), y)
     with pytest.raises(ValueError):
         m.train_on_batch(x[:1], [a[:1] for a in yl])  # a BatchNorm batch needs two samples

@@ -61,3 +61,37 @@ def test_adam_first_step_is_sign_descent():
     nw, m, v = cnn_mtl_train.adam_step(w, g, {}, {}, {"a": (np.array([1.5]), np.array([2.0]))}, step=1, lr=1e-2)
     np.testing.assert_allclose(nw["a/kernel"], w["a/kernel"] - 1e-2 * np.sign(g["a/kernel"]), atol=1e-4)
     np.testing.assert_allclose(nw["a/moving_mean"], [0.99 * 0.5 + 0.01 * 1.5])
+
+
+def test_papakostas_training_forward_matches_inference_oracle():
+    N, H, W = 5, 61, 68
+    w = cnn_mtl.init_papakostas(seed=4, H=H, W=W, fc=64)
+    x, y = _batch(N, H, W, 3)
+    out = cnn_mtl_train.forward_backward(x, y, w, kind="Papakostas")
+    w2 = dict(w)
+    for p, (mean, var) in out["bn_batch"].items():  # Dense layers only: population variance
+        w2[p + "/moving_mean"], w2[p + "/moving_variance"] = mean.astype(np.float32), var.astype(np.float32)
+    _, feat = cnn_mtl.forward_papakostas(x[..., None], w2, return_features=True)
+    np.testing.assert_allclose(feat, out["features"], atol=2e-4)
+    g = out["grads"]
+    assert np.abs(g["conv1/bias"]).max() > 0 and np.abs(g["conv2/kernel"]).max() > 0  # no BatchNorm: real bias gradients
+    nw = cnn_mtl_train.sgd_step(w, g, out["bn_batch"], 1e-3)
+    assert np.allclose(nw["conv3/bias"], w["conv3/bias"] - 1e-3 * g["conv3/bias"])
+
+
+def test_jang_training_forward_matches_inference_oracle():
+    N, W = 3, 12
+    w = cnn_mtl.init_jang(seed=2, W=W, mel_init=False)
+    x, y = _batch(N, 514, W, 4)
+    out = cnn_mtl_train.forward_backward(x, y, w, kind="Jang")
+    w2 = dict(w)
+    sizes = {"bn1": N * 240 * 12, "bn2": N * 120 * 6, "bn3": N * 60 * 3}
+    for p, (mean, var) in out["bn_batch"].items():
+        if p in sizes:
+            var = var * (sizes[p] - 1.0) / sizes[p]
+        w2[p + "/moving_mean"], w2[p + "/moving_variance"] = mean.astype(np.float32), var.astype(np.float32)
+    _, (_, feat) = cnn_mtl.forward_jang(x[..., None], w2, return_features=True)
+    np.testing.assert_allclose(feat, out["features"], atol=2e-4)
+    names = cnn_mtl_train.l2_names("Jang", w)
+    assert len(names) == 240 + 3 + 2 + 1 + 3 and out["l2"] == pytest.approx(0.01 * sum(float((w[k].astype(np.float64) ** 2).sum()) for k in names))
+    assert np.abs(out["grads"]["harm_melCl7/kernel"]).max() > 0 and np.abs(out["grads"]["perc_melCl119/kernel"]).max() > 0
