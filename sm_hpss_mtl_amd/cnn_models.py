@@ -39,7 +39,7 @@ class CnnMTL(CnnTrainingMixin):
         self.in_h, self.in_w = int(input_shape[0]), int(input_shape[1])
         if len(input_shape) > 2 and int(input_shape[2]) != 1:
             raise ValueError("input_shape must be (H, W, 1), got %s" % (tuple(input_shape),))
-        self.n_mels, self.n_fft, self.fs = int(n_mels), int(n_fft), float(fs)
+        self.n_mels, self.n_fft, self.fs, self.fc_width = int(n_mels), int(n_fft), float(fs), int(fc_width)
         cfg = _lib.CnnCfg(KINDS[kind], self.in_h, self.in_w, self.n_classes, self.n_mels, self.n_fft, int(fc_width),
                           self.fs)
         h = C.c_void_p()
@@ -179,7 +179,7 @@ class CnnMTL(CnnTrainingMixin):
     def to_json(self):
         return json.dumps({"class_name": self.kind + "_MTL", "config": {
             "input_shape": [self.in_h, self.in_w, 1], "n_classes": self.n_classes, "n_mels": self.n_mels,
-            "n_fft": self.n_fft, "fs": self.fs, "outputs": self.output_names}})
+            "n_fft": self.n_fft, "fs": self.fs, "fc_width": self.fc_width, "outputs": self.output_names}})
 
     def summary(self, print_fn=print):
         print_fn("Model: %s_MTL, input (None, %d, %d, 1)" % (self.kind, self.in_h, self.in_w))

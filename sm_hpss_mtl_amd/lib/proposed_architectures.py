@@ -38,3 +38,7 @@ def get_Jang_MTL_model(PARAMS, fs=16000, Tw=25, n_mels=120, t_dim=5, n_classes=3
     model = CnnMTL("Jang", PARAMS["input_shape"][PARAMS["Model"]], n_classes=n_classes, seed=seed, n_mels=n_mels,
                    n_fft=PARAMS["n_fft"][PARAMS["Model"]], fs=fs)
     return model, model.initial_learning_rate
+
+
+# tensorflow.keras.models.model_from_json at the reference's call site (Proposed_Work_Results.py:381-383)
+from ..persistence import model_from_json  # noqa: E402,F401

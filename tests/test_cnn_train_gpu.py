@@ -249,3 +249,31 @@ def test_fit_reduces_the_loss():
     assert m.evaluate(x, yl)[0] < first[0]
     with pytest.raises(ValueError):
         m.train_on_batch(x[:1], [a[:1] for a in yl])  # a BatchNorm batch needs two samples
+
+
+def test_persistence_round_trip(tmp_path):
+    """Proposed_Work_Results.py:370-384: save_weights + to_json + params.npz, then model_from_json + load_weights."""
+    from sm_hpss_mtl_amd.lib.proposed_architectures import model_from_json
+    from sm_hpss_mtl_amd.model import B3MTL
+    m, _ = _model(30, 68, seed=9)
+    x, y = _batch(6, 30, 68, 3)
+    m.train_on_batch(x, y)  # the device copy becomes the master
+    wfile, afile, pfile = str(tmp_path / "w.h5"), str(tmp_path / "arch.json"), str(tmp_path / "params.npz")
+    m.save_weights(wfile)
+    open(afile, "w").write(m.to_json())
+    np.savez(pfile, epochs=50, batch_size=16, lr=m.initial_learning_rate, trainingTimeTaken=1.5)
+    m2 = model_from_json(open(afile).read())
+    m2.load_weights(wfile)
+    assert float(np.load(pfile)["lr"]) == 1e-4 and m2.kind == "Doukhan" and m2.input_shape == m.input_shape
+    for a, b in zip(m.predict(x), m2.predict(x)):  # same weights; the epilogue constants were folded on the device / on the host
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    for k, v in m.get_weights_dict().items():
+        assert np.array_equal(v, m2.get_weights_dict()[k]), k
+    b3 = B3MTL(n_feat=240, patch_size=68, n_classes=5, seed=1)
+    b3b = model_from_json(b3.to_json())
+    b3.save_weights(str(tmp_path / "b3"))
+    b3b.load_weights(str(tmp_path / "b3"))
+    xb = np.random.default_rng(0).normal(size=(3, 68, 240)).astype(np.float32)
+    assert b3b.dropout_rate == b3.dropout_rate and b3b.output_names == ["S", "M", "N", "R", "3C"]
+    for a, b in zip(b3.predict(xb), b3b.predict(xb)):
+        assert np.array_equal(a, b)
