@@ -15,7 +15,8 @@ constexpr int kMaxG = 16;      // patches per workgroup <= MFMA N
 constexpr int kPS = 80;        // row stride of the Dense-on-trunk outputs: up to 5 M-tiles (5-class: 69 outputs)
 constexpr float kNormEps = 1e-5f;
 constexpr float kBnEps = 1e-3f;
-// Packed per-block weights: [conv A: 24 steps x 2 M-tiles x 64 lanes][1x1 A: 8 x 2 x 64][b1 32][b2 32]
+// Packed per-block weights: 64 A-operand slots per lane (48 dilated-conv + 16 1x1), four slots per lane contiguous
+// ([slot / 4][lane][slot % 4], see load_block_lds), then [b1 32][b2 32]
 constexpr int kBlockFloats = 24 * 2 * 64 + 8 * 2 * 64 + 32 + 32;
 
 struct TcnArgs {

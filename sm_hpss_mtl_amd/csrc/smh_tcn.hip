@@ -13,11 +13,15 @@
 //     to match the accumulator layout) -- no LDS round trip between the two convolutions,
 //   * bias and residual are folded into the accumulator initialisation.
 // One workgroup owns G patches; the activations x (G*T rows x 32 ch, fp32) live in LDS for all
-// 24 blocks (double buffered, one barrier per block).  Weights stream from L2 in MFMA A-operand order
-// and are double-buffered in registers: block b+1's weights are requested before block b is computed.
+// 24 blocks (double buffered, one barrier per block).  Block weights are pre-packed in MFMA A-operand order; the
+// workgroup copies block b+1 from L2 into an LDS slot by LDS-DMA while block b is computed, and every wave reads its
+// 80 operand registers from that slot at the top of the block (one register set: 9..12 waves fit under 170 VGPRs).
+// Waves per workgroup follow the tile count: 17 column tiles (4 patches of 68 frames) run on 9 waves -- 2 tiles each,
+// one wave with 1 -- because with 8 the wave holding 3 tiles sets the time of every block.
 // The Dense layers that read the flattened trunk (3C logits + the Dense(16) of every head) run in the
 // same kernel as one more MFMA product D[output][patch] on the LDS-resident activations; BN / relu /
 // output Dense / sigmoid / softmax finish in a few threads.  One launch per forward.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,21 +37,39 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// max over the four lanes that hold the same time step (l, l^16, l^32, l^48): gfx950's VALU lane swaps instead of two
+// ds_bpermute round trips
+__device__ __forceinline__ float quad_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    const unsigned ua = __float_as_uint(a);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+}
+
+constexpr bool kRotate = false;  // with 9 waves the light wave must stay on the SIMD that hosts three of them
+
 struct BlockW {
     float wc[24][2], wp[8][2];
     f32x4 b1lo, b1hi, b2lo, b2hi;
 };
 
-__device__ __forceinline__ void load_block(BlockW &w, const float *__restrict__ wblk, int lane, int q) {
+// Block weights, LDS -> registers.  The workgroup's LDS copy of the block is staged by LDS-DMA one block ahead: every wave
+// needs the whole block, so the 16.6 KB come from L2 once per workgroup instead of once per wave.  Packed order
+// (pack_weights below): operand slot n = 2 s + mt (dilated conv, s < 24) or 48 + 2 e + mt (1x1 conv, e < 8) of lane l
+// sits at [(n / 4) * 256 + 4 l + n % 4], so one ds_read_b128 per lane delivers four slots, conflict-free.
+__device__ __forceinline__ void load_block_lds(BlockW &w, const float *wblk, int lane, int q) {
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(wblk) + lane;
 #pragma unroll
-    for (int s = 0; s < 24; ++s) {
-        w.wc[s][0] = wblk[(s * 2 + 0) * 64 + lane];
-        w.wc[s][1] = wblk[(s * 2 + 1) * 64 + lane];
+    for (int g = 0; g < 12; ++g) {
+        const f32x4 v = wv[g * 64];
+        w.wc[2 * g][0] = v[0], w.wc[2 * g][1] = v[1], w.wc[2 * g + 1][0] = v[2], w.wc[2 * g + 1][1] = v[3];
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        w.wp[s][0] = wblk[24 * 2 * 64 + (s * 2 + 0) * 64 + lane];
-        w.wp[s][1] = wblk[24 * 2 * 64 + (s * 2 + 1) * 64 + lane];
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = wv[(12 + g) * 64];
+        w.wp[2 * g][0] = v[0], w.wp[2 * g][1] = v[1], w.wp[2 * g + 1][0] = v[2], w.wp[2 * g + 1][1] = v[3];
     }
     const float *b1 = wblk + 24 * 2 * 64 + 8 * 2 * 64;
     w.b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
@@ -92,8 +114,7 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
             acc1[r] = fmaxf(acc1[r], 0.f);
             mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = quad_max(mx);
         const float inv = 1.0f / (mx + kNormEps);
         f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
         if constexpr (TRAIN) {
@@ -126,7 +147,7 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
 }
 
 template <bool TRAIN>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(768)
 b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
                      const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
                      float *__restrict__ out, TrainIO tio) {
@@ -212,10 +233,22 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         }
     }
 
-    BlockW wA, wB;
-    load_block(wA, Wb, lane, q);
-
-    // ---- residual blocks, two per iteration so that both weight sets have static register names ----
+    // ---- residual blocks.  Block weights: global -> LDS by LDS-DMA one block ahead (two LDS slots), LDS -> registers
+    // at the top of the block ----
+    float *ws = lds + 2 * (size_t)a.GRP * SX;
+    auto stage = [&](int blk) {
+        const char *src = reinterpret_cast<const char *>(Wb + (size_t)blk * kBlockFloats);
+        char *dst = reinterpret_cast<char *>(ws + (size_t)(blk & 1) * kBlockFloats);
+        constexpr int nch = kBlockFloats * 4 / 16;
+        for (int i = wave; i * 64 < nch; i += nw) {
+            const int c = i * 64 + lane;
+            if (c < nch)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 16),
+                                                 (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+    BlockW w;
     float *xin = xa, *xout = xb;
     const int nslot = a.n_blocks + 1;
     auto save_acts = [&](const float *src, int slot) {  // block input -> acts[n][slot][t][c]
@@ -230,23 +263,21 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     };
     const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
     const int dstride = a.n_blocks * C;
-    for (int blk = 0; blk < a.n_blocks; blk += 2) {
-        if (blk + 1 < a.n_blocks) load_block(wB, Wb + (size_t)(blk + 1) * kBlockFloats, lane, q);
-        __syncthreads();  // xin complete
+    for (int blk = 0; blk < a.n_blocks; ++blk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
+        __syncthreads();                                  // xin complete, every wave's share has landed
+        load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
+        // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
+        if (blk + 1 < a.n_blocks) stage(blk + 1);
         save_acts(xin, blk);
-        run_block<TRAIN>(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout,
+        // the wave that gets the odd unit out rotates with the block and the workgroup, so that over time (and across
+        // the workgroups sharing a CU) every SIMD carries the same load
+        const int rot = kRotate ? (int)blockIdx.x + blk : 0;
+        run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, units, (wave + rot) % nw, nw, q, j, xin, xout,
                          drop0 ? drop0 + (size_t)blk * C : nullptr, dstride);
-        if (blk + 1 < a.n_blocks) {
-            if (blk + 2 < a.n_blocks) load_block(wA, Wb + (size_t)(blk + 2) * kBlockFloats, lane, q);
-            __syncthreads();
-            save_acts(xout, blk + 1);
-            run_block<TRAIN>(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin,
-                             drop0 ? drop0 + (size_t)(blk + 1) * C : nullptr, dstride);
-        } else {
-            float *tmp = xin;
-            xin = xout;
-            xout = tmp;
-        }
+        float *tmp = xin;
+        xin = xout;
+        xout = tmp;
     }
     __syncthreads();
     save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
@@ -410,14 +441,16 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
                 for (int lane = 0; lane < 64; ++lane) {
                     const int q = lane >> 4, i = lane & 15;
                     const int tap = s / 8, c = (4 * s) % 32 + q;
-                    wb[(s * 2 + mt) * 64 + lane] = k1[((size_t)tap * C + c) * C + 16 * mt + i];
+                    const int n = s * 2 + mt;
+                    wb[(n / 4) * 256 + 4 * lane + n % 4] = k1[((size_t)tap * C + c) * C + 16 * mt + i];
                 }
         for (int e = 0; e < 8; ++e)
             for (int mt = 0; mt < 2; ++mt)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int q = lane >> 4, i = lane & 15;
                     const int cin = 16 * (e / 4) + 4 * q + (e % 4);
-                    wb[24 * 2 * 64 + (e * 2 + mt) * 64 + lane] = k2[(size_t)cin * C + 16 * mt + i];
+                    const int n = 48 + e * 2 + mt;
+                    wb[(n / 4) * 256 + 4 * lane + n % 4] = k2[(size_t)cin * C + 16 * mt + i];
                 }
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64, b1, C * sizeof(float));
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64 + 32, b2, C * sizeof(float));
@@ -513,7 +546,7 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     if (GRP * SX < m->FQ * 2 * 64) GRP = (m->FQ * 2 * 64 + SX - 1) / SX;  // layer-0 A operands are staged there
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
-    *plds = sizeof(float) * 2 * (size_t)GRP * SX;
+    *plds = sizeof(float) * (2 * (size_t)GRP * SX + 2 * (size_t)kBlockFloats);  // activations (x2) + two weight slots
 }
 
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
@@ -525,7 +558,15 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
     a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
-    const dim3 grid((N + a.G - 1) / a.G), block(512);
+    // waves per workgroup: the block time is (column tiles of the busiest wave) x (time per tile) plus a fixed part, so
+    // take the fewest waves in 8..12 that minimise ceil(tiles / waves): 17 tiles (4 patches of 68 frames) -> 9 waves,
+    // 2 tiles each and one with 1, instead of 8 waves of which one does 3
+    const int units = (std::min(a.G, N) * a.T + 15) / 16;
+    int nwaves = 8;
+    for (int w = 9; w <= 12; ++w)
+        if ((units + w - 1) / w < (units + nwaves - 1) / nwaves) nwaves = w;
+    if (const char *ev = getenv("SMH_TCN_WAVES")) nwaves = std::max(4, std::min(12, atoi(ev)));  // tuning only
+    const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
     if (tio) {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
