@@ -277,3 +277,34 @@ def test_persistence_round_trip(tmp_path):
     assert b3b.dropout_rate == b3.dropout_rate and b3b.output_names == ["S", "M", "N", "R", "3C"]
     for a, b in zip(b3.predict(xb), b3b.predict(xb)):
         assert np.array_equal(a, b)
+
+
+def test_trainer_c_abi_errors():
+    """Argument checking at the C boundary: status codes + smh_last_error, nothing launched."""
+    import ctypes as C
+    import torch
+    from sm_hpss_mtl_amd import _lib
+    lib = _lib.require_gpu()
+    m, _ = _model(30, 68)
+    h = C.c_void_p()
+    assert lib.smh_cnn_trainer_create(m._h, 1, C.byref(h)) < 0 and b"at least 2" in lib.smh_last_error()
+    assert lib.smh_cnn_trainer_create(None, 8, C.byref(h)) < 0
+    assert lib.smh_cnn_trainer_create(m._h, 8, C.byref(h)) == 0
+    try:
+        assert lib.smh_cnn_trainer_num_dropouts(h) == 4
+        dim, rate = C.c_size_t(), C.c_float()
+        assert lib.smh_cnn_trainer_dropout_info(h, 3, C.byref(dim), C.byref(rate)) == 0 and dim.value == 512 and rate.value == 0.5
+        assert lib.smh_cnn_trainer_dropout_info(h, 4, C.byref(dim), C.byref(rate)) < 0
+        x = torch.zeros((9, 30, 68), device="cuda")
+        y = torch.zeros((9, m.out_dim), device="cuda")
+        losses = torch.zeros(8, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        assert lib.smh_cnn_train_step_f32(h, p(x), p(y), 9, None, None, None, p(losses), None) < 0  # batch > max_batch
+        assert b"outside [2, 8]" in lib.smh_last_error()
+        assert lib.smh_cnn_train_step_f32(h, None, p(y), 4, None, None, None, p(losses), None) < 0
+        assert lib.smh_cnn_trainer_apply_f32(h, 2, 1e-3, 0.9, 0.999, 1e-7, 1.0, None) < 0  # unknown optimiser
+        assert lib.smh_cnn_trainer_apply_f32(None, 1, 1e-3, 0.9, 0.999, 1e-7, 1.0, None) < 0
+        assert lib.smh_cnn_trainer_grad_ptr(h) is not None and lib.smh_cnn_trainer_grad_ptr(None) is None
+    finally:
+        lib.smh_cnn_trainer_destroy(h)
+    lib.smh_cnn_trainer_destroy(None)  # no-op
