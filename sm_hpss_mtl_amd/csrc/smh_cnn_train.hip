@@ -86,19 +86,21 @@ __global__ void __launch_bounds__(256) colred_kernel(RedArgs r, float *__restric
     const size_t row1 = row0 + r.rows_per_block < r.M ? row0 + r.rows_per_block : r.M;
     float *out = partial + (size_t)blockIdx.x * NV * C;
     const int cq = C >> 2;
-    if ((C & 3) == 0 && cq <= 256 && 256 % cq == 0) {
-        const int rp = 256 / cq;  // rows per pass
-        const int c = (tid % cq) * 4, rsub = tid / cq;
+    if ((C & 3) == 0 && ((cq <= 256 && 256 % cq == 0) || cq % 256 == 0)) {
+        // narrow matrices: 256 / cq rows per pass; wide ones (Dense 1024 / 2048 / 4096): blockIdx.y picks a 1024-column slab
+        const int cqb = cq < 256 ? cq : 256;
+        const int rp = 256 / cqb;  // rows per pass
+        const int c = (blockIdx.y * 256 + tid % cqb) * 4, rsub = tid / cqb;
         f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
         for (size_t row = row0 + rsub; row < row1; row += rp) red_item4<F>(r, row * C + c, c, v0, v1);
         sh[0][tid] = v0;
         if (NV == 2) sh[NV - 1][tid] = v1;
         __syncthreads();
-        if (tid < cq) {
+        if (tid < cqb) {
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
             for (int q = 0; q < rp; ++q) {
-                s0 += sh[0][q * cq + tid];
-                if (NV == 2) s1 += sh[NV - 1][q * cq + tid];
+                s0 += sh[0][q * cqb + tid];
+                if (NV == 2) s1 += sh[NV - 1][q * cqb + tid];
             }
             *reinterpret_cast<f32x4 *>(out + c) = s0;
             if (NV == 2) *reinterpret_cast<f32x4 *>(out + C + c) = s1;
@@ -533,15 +535,24 @@ __global__ void __launch_bounds__(256) opt_kernel(const Seg *__restrict__ segs, 
         }
     }
 }
-__global__ void __launch_bounds__(1024) l2_penalty_kernel(const Seg *__restrict__ segs, int nseg, const float *__restrict__ w,
-                                                          float *__restrict__ out) {
+// l2(0.01) penalty of the regularised kernels: one workgroup per optimiser segment (<= 64 K weights) sums w^2 in f64,
+// a second launch adds the per-segment sums in order.  (Jang regularises all 74 M weights: a single workgroup took 30 ms.)
+__global__ void __launch_bounds__(256) l2_partial_kernel(const Seg *__restrict__ segs, const float *__restrict__ w,
+                                                         double *__restrict__ partial) {
+    __shared__ double sh[4];
+    const Seg sg = segs[blockIdx.x];
+    double s = 0.0;
+    if (sg.kind == 1)
+        for (unsigned i = threadIdx.x; i < sg.size; i += blockDim.x) s += (double)w[sg.off + i] * (double)w[sg.off + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void __launch_bounds__(1024) l2_finish_kernel(const double *__restrict__ partial, int nseg, float *__restrict__ out) {
     __shared__ double sh[16];
     double s = 0.0;
-    for (int q = 0; q < nseg; ++q) {
-        const Seg sg = segs[q];
-        if (sg.kind != 1) continue;
-        for (unsigned i = threadIdx.x; i < sg.size; i += blockDim.x) s += (double)w[sg.off + i] * (double)w[sg.off + i];
-    }
+    for (int q = threadIdx.x; q < nseg; q += blockDim.x) s += partial[q];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -602,6 +613,7 @@ struct smh_cnn_trainer {
     float *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr, *d_scratch = nullptr;
     float *d_grad = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_bstat = nullptr;
     int2 *d_tables = nullptr;
+    double *d_l2part = nullptr;
     Seg *d_segs = nullptr;
     FoldEnt *d_foldents = nullptr;
     int nseg = 0, nfold = 0;
@@ -637,8 +649,9 @@ int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, flo
                hipStream_t st) {
     const int C = r.C;
     const int cq = C >> 2;
-    const bool vec = (C & 3) == 0 && cq <= 256 && 256 % cq == 0;  // the kernel's own test
-    const size_t rows_per_pass = vec ? 256 / cq : 1;
+    const bool vec = (C & 3) == 0 && ((cq <= 256 && 256 % cq == 0) || cq % 256 == 0);  // the kernel's own test
+    const size_t rows_per_pass = vec ? (cq < 256 ? 256 / cq : 1) : 1;
+    const unsigned slabs = vec && cq > 256 ? cq / 256 : 1;
     size_t rpb = vec ? rows_per_pass * 16 : 64;
     size_t nb = (r.M + rpb - 1) / rpb;
     if (nb > kMaxRed) {
@@ -647,7 +660,7 @@ int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, flo
         nb = (r.M + rpb - 1) / rpb;
     }
     r.rows_per_block = (int)rpb;
-    hipLaunchKernelGGL(colred_kernel<F>, dim3((unsigned)nb), dim3(256), 0, st, r, t->d_red);
+    hipLaunchKernelGGL(colred_kernel<F>, dim3((unsigned)nb, slabs), dim3(256), 0, st, r, t->d_red);
     hipLaunchKernelGGL(colred_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, st, (const float *)t->d_red, (int)nb, C, nv, scale,
                        mode, bessel, r.mean, dst0, dst1);
     return smh::launch_status("colred_kernel");
@@ -661,6 +674,7 @@ extern "C" void smh_cnn_trainer_destroy(smh_cnn_trainer *t) {
                      t->d_dpre, t->d_dxh, t->d_scratch, t->d_grad, t->d_s1, t->d_s2, t->d_bstat})
         (void)hipFree(p);
     (void)hipFree(t->d_tables);
+    (void)hipFree(t->d_l2part);
     (void)hipFree(t->d_segs);
     (void)hipFree(t->d_foldents);
     delete t;
@@ -813,6 +827,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         }
         t->nseg = (int)segs.size(), t->nfold = (int)folds.size();
         e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Seg));
+        if (e == hipSuccess) e = hipMalloc((void **)&t->d_l2part, segs.size() * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&t->d_foldents, std::max<size_t>(folds.size(), 1) * sizeof(FoldEnt));
         if (e == hipSuccess) e = hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice);
         if (e == hipSuccess && !folds.empty()) e = hipMemcpy(t->d_foldents, folds.data(), folds.size() * sizeof(FoldEnt), hipMemcpyHostToDevice);
@@ -953,7 +968,8 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
     rc = smh_tcn::launch_heads_train(ha, t->d_pre, d_y, F, d_drop_heads, t->d_dpre, t->d_dxh, t->d_grad,
                                      t->d_bstat + t->head_bstat, d_losses, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(l2_penalty_kernel, dim3(1), dim3(1024), 0, st, (const Seg *)t->d_segs, t->nseg, F, d_losses + m->n_heads + 3);
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(t->nseg), dim3(256), 0, st, (const Seg *)t->d_segs, F, t->d_l2part);
+    hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(1024), 0, st, (const double *)t->d_l2part, t->nseg, d_losses + m->n_heads + 3);
     hipLaunchKernelGGL(heads_dw_kernel, dim3(nblk((size_t)m->feat_dim * kHidden), 1 + m->n_heads), dim3(256), 0, st, feat,
                        (const float *)t->d_dpre, hp, N, t->d_grad);
     int cur = 0;

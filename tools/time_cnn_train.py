@@ -9,13 +9,16 @@ import torch
 sys.path.insert(0, ".")
 from sm_hpss_mtl_amd.cnn_models import CnnMTL  # noqa: E402
 
-FWD_GFLOP = 1.906  # per 240 x 68 patch (oracle.cnn_mtl.flops_per_patch("Doukhan", 240, 68))
+# forward GFLOP per patch (2 x MACs of every Conv2D / Dense at the reference's input size)
+SHAPES = {"Doukhan": ((240, 68), 1.906), "Papakostas": ((402, 68), 0.755), "Jang": ((514, 68), 0.479)}
 PEAK = 157.3e12
+kinds = sys.argv[1:] or ["Doukhan"]
 
-for N in (48, 192):
-    m = CnnMTL("Doukhan", (240, 68, 1), seed=0)
+for kind, N in [(k, n) for k in kinds for n in (48, 192)]:
+    (H, W), FWD_GFLOP = SHAPES[kind]
+    m = CnnMTL(kind, (H, W, 1), seed=0)
     rng = np.random.default_rng(0)
-    x = torch.from_numpy(rng.normal(size=(N, 240, 68)).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.normal(size=(N, H, W)).astype(np.float32)).cuda()
     c = np.arange(N) % 3
     y = m.pack_targets([(c == 1).astype(np.float32)[:, None], (c == 0).astype(np.float32)[:, None],
                         rng.uniform(size=(N, 2)).astype(np.float32), np.eye(3, dtype=np.float32)[c]])
@@ -28,5 +31,5 @@ for N in (48, 192):
         m.train_on_batch(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    print("N=%d: %.2f ms/step = %.0f patches/s, %.1f%% of the f32 MFMA peak (3 x forward flops)"
-          % (N, dt * 1e3, N / dt, 100 * 3 * FWD_GFLOP * 1e9 * N / dt / PEAK), flush=True)
+    print("%s N=%d: %.2f ms/step = %.0f patches/s, %.1f%% of the f32 MFMA peak (3 x forward flops)"
+          % (kind, N, dt * 1e3, N / dt, 100 * 3 * FWD_GFLOP * 1e9 * N / dt / PEAK), flush=True)
