@@ -247,7 +247,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                                                  (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
         }
     };
-    stage(0);
+    if (a.wlds) stage(0);
     BlockW w;
     float *xin = xa, *xout = xb;
     const int nslot = a.n_blocks + 1;
@@ -264,11 +264,16 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
     const int dstride = a.n_blocks * C;
     for (int blk = 0; blk < a.n_blocks; ++blk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
-        __syncthreads();                                  // xin complete, every wave's share has landed
-        load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
-        // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
-        if (blk + 1 < a.n_blocks) stage(blk + 1);
+        if (a.wlds) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
+            __syncthreads();                                  // xin complete, every wave's share has landed
+            load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
+            // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
+            if (blk + 1 < a.n_blocks) stage(blk + 1);
+        } else {  // very long patches: no LDS left for the weight slots, every wave reads the block from L2
+            __syncthreads();
+            load_block_lds(w, Wb + (size_t)blk * kBlockFloats, lane, q);
+        }
         save_acts(xin, blk);
         // the wave that gets the odd unit out rotates with the block and the workgroup, so that over time (and across
         // the workgroups sharing a CU) every SIMD carries the same load
@@ -546,7 +551,9 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     if (GRP * SX < m->FQ * 2 * 64) GRP = (m->FQ * 2 * 64 + SX - 1) / SX;  // layer-0 A operands are staged there
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
-    *plds = sizeof(float) * (2 * (size_t)GRP * SX + 2 * (size_t)kBlockFloats);  // activations (x2) + two weight slots
+    const size_t lds_x = sizeof(float) * 2 * (size_t)GRP * SX, lds_w = sizeof(float) * 2 * (size_t)kBlockFloats;
+    a.wlds = lds_x + lds_w <= 156 * 1024 ? 1 : 0;  // activations (x2) + two weight slots, when they fit
+    *plds = lds_x + (a.wlds ? lds_w : 0);
 }
 
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,

@@ -290,7 +290,8 @@ def test_fused_patches_vs_oracle(fe, clips4, W, shift):
 # ---------------------------------------------------------------------------------------------------
 # a10-a12 B3_MTL forward
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("ncls,W,N", [(3, 68, 6), (5, 68, 6), (3, 99, 6), (3, 249, 3), (3, 68, 1030), (5, 68, 1030), (5, 99, 700)])
+@pytest.mark.parametrize("ncls,W,N", [(3, 68, 6), (5, 68, 6), (3, 99, 6), (3, 249, 3), (3, 68, 1030), (5, 68, 1030), (5, 99, 700),
+                                      (3, 500, 2)])  # 500 frames: no LDS left for the weight slots (per-wave weight reads)
 def test_b3mtl_forward_vs_oracle(golden_model, ncls, W, N):
     from sm_hpss_mtl_amd.model import B3MTL
     w = b3_mtl.init_weights(seed=7, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
