@@ -572,6 +572,9 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
     float *s_mean = img + (size_t)R2 * ld;  // mean hi [R2], 1/scale [R2], mean lo [R2]
     float *s_inv = s_mean + R2, *s_lo = s_mean + 2 * R2;
     int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)R2);  // 32 ints
+    float *w0s = s_mean + 3 * (size_t)R2 + 32;  // layer-0 weights [R2][32] (x0p only)
+    if (x0p)  // consumed after several barriers
+        for (int i = threadIdx.x; i < R2 * 32; i += blockDim.x) w0s[i] = w0[i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const size_t cb = (size_t)b * K * T;
     const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
@@ -704,12 +707,17 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         s_lo[r] = (float)(mean - (double)(float)mean);
     }
     __syncthreads();
-    if (x0p) {  // the network's first layer, per clip half (std_patch_kernel<true> has the derivation)
+    if (x0p) {
+        // The network's first layer, per clip half (std_patch_kernel<true> has the derivation):
+        // x0p[half][t][c] = sum_r W0[half*rows + r][c] * standardised(img[half*rows + r][t]).  One task = one 16-frame tile
+        // of one half, BOTH 16-channel M-tiles (they share the B operand, the standardised value); the layer's
+        // weights were copied to LDS at kernel start.  Steps run in branch-free groups of 8 (steps past the last row
+        // multiply a zero), so the LDS reads of a group are all in flight before its first product.
         const int q = lane >> 4, j = lane & 15;
         const int ut = (W + 15) >> 4;
-        constexpr int kMaxSt = 32;  // rows <= 128: every weight of the task is requested before the first product
-        for (int task = wave; task < nP * ut * 4; task += nw) {
-            const int mt = task & 1, half = (task >> 1) & 1, pu = task >> 2;
+        const int nst = rows / 4;
+        for (int task = wave; task < nP * ut * 2; task += nw) {
+            const int half = task & 1, pu = task >> 1;
             const int p = pu / ut, u = pu - p * ut;
             int s = p * shift;
             const int e = min(s + W, Ttiled);
@@ -717,26 +725,41 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
             const int jt = 16 * u + j;
             int tt = s + min(jt, W - 1);
             tt -= (tt / T) * T;
-            const float *wr = w0 + ((size_t)half * rows + q) * 32 + 16 * mt + j;
-            const float *tl = img + (size_t)half * rows * ld;
+            const float *wr = w0s + ((size_t)half * rows + q) * 32 + j;
+            const float *tl = img + (size_t)half * rows * ld + tt;
             const float *mh = s_mean + half * rows, *ml = s_lo + half * rows, *iv = s_inv + half * rows;
-            const int nst = rows / 4;
-            float wa[kMaxSt];
+            f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = c0a, c1a = c0a, c1b = c0a;  // two chains per M-tile
+            for (int s0 = 0; s0 < nst; s0 += 8) {
+                float xs[8], is[8], wa0[8], wa1[8], hs[8], ls[8];
 #pragma unroll
-            for (int st = 0; st < kMaxSt; ++st) wa[st] = wr[(size_t)(4 * min(st, nst - 1)) * 32];
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};  // two chains: MFMA latency > issue
+                for (int g = 0; g < 8; ++g) {
+                    const int r = 4 * min(s0 + g, nst - 1) + q;
+                    xs[g] = tl[r * ld];
+                    hs[g] = mh[r], ls[g] = ml[r];
+                    is[g] = s0 + g < nst ? iv[r] : 0.f;
+                    wa0[g] = wr[(size_t)(r - q) * 32];
+                    wa1[g] = wr[(size_t)(r - q) * 32 + 16];
+                }
 #pragma unroll
-            for (int st = 0; st < kMaxSt; ++st) {
-                if (st < nst) {
-                    const int r = 4 * st + q;
-                    const float c = (float)((double)tl[r * ld + tt] - ((double)mh[r] + (double)ml[r]));
-                    if (st & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st], c * iv[r], c1, 0, 0, 0);
-                    else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st], c * iv[r], c0, 0, 0, 0);
+                for (int g = 0; g < 8; ++g) {
+                    // x - mean with the f64 mean held as hi + lo floats: two f32 subtractions (the f64 form of the patch
+                    // writer costs four quarter-rate instructions per value and made this phase VALU-bound)
+                    const float c = __fsub_rn(__fsub_rn(xs[g], hs[g]), ls[g]) * is[g];
+                    if (g & 1) {
+                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[g], c, c0b, 0, 0, 0);
+                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[g], c, c1b, 0, 0, 0);
+                    } else {
+                        c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[g], c, c0a, 0, 0, 0);
+                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[g], c, c1a, 0, 0, 0);
+                    }
                 }
             }
-            c0 += c1;
-            if (jt < W)
-                *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 16 * mt + 4 * q) = c0;
+            c0a += c0b, c1a += c1b;
+            if (jt < W) {
+                float *o = x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q;
+                *reinterpret_cast<f32x4 *>(o) = c0a;
+                *reinterpret_cast<f32x4 *>(o + 16) = c1a;
+            }
         }
     }
     if (!patches) return;
@@ -816,7 +839,8 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
     const int K = c->K, rows = c->feat_rows;
     if (!c->feat_walk_ok || getenv("SMH_FEAT_TAPS")) return 0;
     if (x0p && (rows % 4 != 0 || rows > 128)) return 0;
-    const size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
+    size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
+    if (x0p) lds += sizeof(float) * 2 * rows * 32;  // the layer's weights
     if (lds > 158 * 1024) return 0;
     FeatPlan fp;
     fp.nseg = c->feat_nseg[1];
