@@ -10,7 +10,8 @@ torch.distributed.run), every rank owns its own 1024 clips -- clips are independ
 no collective on the data path (weak scaling); only the timing barrier/all-reduce uses RCCL.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step; per-kernel
-figures for every stage are in `kernels`.  `cpu_baseline` times the numpy oracle ("port") on a bounded
+figures for every stage are in `kernels`: HIP events on the launch stream around every stage, recorded inside
+the timed region on every 4th step (`--event-every`; five markers per step cost ~10 us).  `cpu_baseline` times the numpy oracle ("port") on a bounded
 sample of the same workload on this host (rank 0, N=1 only).
 """
 import argparse
@@ -77,6 +78,9 @@ def main():
                          "of computing the network's first 1x1 convolution inside the feature kernel")
     ap.add_argument("--two-kernel-features", action="store_true",
                     help="time-major harm + hp_feat_walk / std_patch kernels instead of the single feature kernel")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="record the per-kernel HIP events on every n-th timed step (the markers of all five stages cost "
+                         "about 10 us per step, 2 %% of it; the other timed steps run without them)")
     ap.add_argument("--model-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = mixed-precision network (BASELINE config 5); NOT the parity path, never the default")
     args = ap.parse_args()
@@ -165,8 +169,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    sampled = [k for k in range(args.steps) if k % max(1, args.event_every) == 0]
     for k in range(args.steps):
-        step(ev[k])
+        step(ev[k] if k in sampled else None)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -176,7 +181,7 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(logits).all(), "non-finite logits"
 
-    ms = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
+    ms = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in sampled])) for i, n in enumerate(names)}
     kernels = {}
     for n in ("stft", "median", "features"):
         nbytes = BYTES[n]
