@@ -141,13 +141,14 @@ class B3MTL(TrainingMixin):
         self.set_weights([d[n] for n, _, _, _ in self._spec])
 
     def save_weights(self, path):
+        """`.h5` / `.hdf5`: HDF5 in Keras' weight-file layout (persistence.py); otherwise `<path>.npz`."""
+        from .persistence import save_weights_file
         self._pull_weights()
-        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **{k.replace("/", "__"): v for k, v in self.weights.items()})
+        return save_weights_file(path, self.weights)
 
     def load_weights(self, path):
-        p = path if str(path).endswith(".npz") else str(path) + ".npz"
-        with np.load(p) as z:
-            self.set_weights_dict({k.replace("__", "/"): z[k] for k in z.files})
+        from .persistence import load_weights_file
+        self.set_weights_dict(load_weights_file(path))
 
     def to_json(self):
         return json.dumps({"class_name": "B3_MTL", "config": {

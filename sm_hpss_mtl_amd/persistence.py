@@ -6,13 +6,44 @@
     ...
     model = model_from_json(open(architechtureFile).read()); model.load_weights(weightFile)
 
-h5py is absent in this environment, so `save_weights(path)` writes `<path>.npz` (tensor names = the Keras weight names
-with '/' spelled '__', canonical order) whatever extension the caller passes -- the reference's `.h5` path argument
-works unchanged; `to_json()` carries the constructor arguments, and `model_from_json` below rebuilds the object.
+`save_weights(path)`: a path ending in `.h5` / `.hdf5` is written as a real HDF5 file in Keras' weight-file layout
+through the system's libhdf5 (`h5io.py`; h5py itself is absent here); anything else -- or a machine without libhdf5 --
+becomes `<path>.npz` (tensor names with '/' spelled '__', canonical order).  `load_weights(path)` takes either.
+`to_json()` carries the constructor arguments, and `model_from_json` below rebuilds the object.
 """
 from __future__ import annotations
 
 import json
+import os
+
+import numpy as np
+
+from . import h5io
+
+
+def save_weights_file(path, weights):
+    """weights: ordered mapping canonical tensor name -> array.  Returns the path written."""
+    path = str(path)
+    if path.endswith((".h5", ".hdf5")) and h5io.available():
+        h5io.write_weights(path, weights)
+        return path
+    p = path if path.endswith(".npz") else path + ".npz"
+    np.savez(p, **{k.replace("/", "__"): v for k, v in weights.items()})
+    return p
+
+
+def load_weights_file(path):
+    """-> dict canonical tensor name -> array, from an HDF5 weight file or the .npz form."""
+    path = str(path)
+    if os.path.isfile(path):
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        if magic == b"\x89HDF\r\n\x1a\n":
+            layers, _ = h5io.read_weights(path)
+            return {name: arr for ws in layers.values() for name, arr in ws.items()}
+    p = path if path.endswith(".npz") else path + ".npz"
+    with np.load(p) as z:
+        return {k.replace("__", "/"): z[k] for k in z.files}
 
 
 def model_from_json(text, seed=None):

@@ -260,6 +260,11 @@ def test_persistence_round_trip(tmp_path):
     m.train_on_batch(x, y)  # the device copy becomes the master
     wfile, afile, pfile = str(tmp_path / "w.h5"), str(tmp_path / "arch.json"), str(tmp_path / "params.npz")
     m.save_weights(wfile)
+    from sm_hpss_mtl_amd import h5io
+    import os
+    assert os.path.exists(wfile) == h5io.available()  # a real HDF5 file where libhdf5 exists, else <path>.npz
+    if h5io.available():
+        assert open(wfile, "rb").read(4) == b"\x89HDF"
     open(afile, "w").write(m.to_json())
     np.savez(pfile, epochs=50, batch_size=16, lr=m.initial_learning_rate, trainingTimeTaken=1.5)
     m2 = model_from_json(open(afile).read())

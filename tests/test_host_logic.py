@@ -133,3 +133,26 @@ def test_label_assembly_matches_reference_rules():
     assert np.allclose(l5["R"][2 * bs + 2], [0.1, 1, 0]) and np.allclose(l5["R"][4 * bs], [0, 1, 10 ** 0.5][:3] if False else l5["R"][4 * bs])
     d = -smr[0]  # +5 dB speech-to-noise
     assert np.allclose(l5["R"][4 * bs], [0, 1 / np.power(10, d / 10), 1])
+
+
+def test_h5_weight_files_round_trip(tmp_path):
+    """Keras-layout HDF5 weight files through libhdf5 (sm_hpss_mtl_amd/h5io.py): structure, names, order, values."""
+    from collections import OrderedDict
+    from sm_hpss_mtl_amd import h5io, persistence
+    if not h5io.available():
+        pytest.skip("libhdf5 not found on this machine")
+    from oracle import b3_mtl
+    w = OrderedDict((k, np.asarray(v, np.float32)) for k, v in b3_mtl.init_weights(seed=2, n_feat=240, patch_size=68, n_classes=5).items())
+    path = str(tmp_path / "weights.h5")
+    assert persistence.save_weights_file(path, w) == path
+    assert open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    layers, attrs = h5io.read_weights(path)
+    assert attrs["backend"] == b"tensorflow" and list(layers) == ["tcn", "3C", "S", "M", "N", "R"] or list(layers)[0] == "tcn"
+    flat = [n for ws in layers.values() for n in ws]
+    assert sorted(flat) == sorted(w) and len(flat) == len(w)
+    back = persistence.load_weights_file(path)
+    for k, v in w.items():
+        assert back[k].dtype == np.float32 and np.array_equal(back[k], v), k
+    # any other extension keeps the .npz form
+    p2 = persistence.save_weights_file(str(tmp_path / "weights"), w)
+    assert p2.endswith(".npz") and np.array_equal(persistence.load_weights_file(str(tmp_path / "weights"))["3C/kernel"], w["3C/kernel"])
