@@ -684,7 +684,12 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
     SMH_REQUIRE(m && out && max_batch >= 2, "smh_cnn_trainer_create: bad argument (a training batch needs at least 2 samples)");
     SMH_REQUIRE(m->cfg.kind == SMH_CNN_DOUKHAN || m->cfg.kind == SMH_CNN_PAPAKOSTAS || m->cfg.kind == SMH_CNN_JANG,
                 "smh_cnn_trainer_create: unknown model kind");
-    smh_cnn_trainer *t = new smh_cnn_trainer();
+    // owned until the end: every early return (SMH_REQUIRE included) releases what has been allocated so far
+    struct Guard {
+        smh_cnn_trainer *p;
+        ~Guard() { smh_cnn_trainer_destroy(p); }
+    } guard{new smh_cnn_trainer()};
+    smh_cnn_trainer *t = guard.p;
     t->m = m, t->max_batch = max_batch;
     const size_t NB = (size_t)max_batch;
     const int nl = (int)m->layers.size();
@@ -722,7 +727,6 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         } else if (L.op == kMelCl && l == 0) {
             arena += S.out_elems * NB;
         } else {
-            delete t;
             return smh::set_error(SMH_E_INVALID, "smh_cnn_trainer_create: layer kind %d has no backward", (int)L.op);
         }
         in_elems = S.out_elems;
@@ -755,10 +759,8 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
     alloc(&t->d_grad, m->n_params), alloc(&t->d_s1, m->n_params), alloc(&t->d_s2, m->n_params);
     alloc(&t->d_bstat, bstat);
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_tables, std::max<size_t>(tables, 1) * sizeof(int2));
-    if (e != hipSuccess) {
-        smh_cnn_trainer_destroy(t);
+    if (e != hipSuccess)
         return smh::set_error(SMH_E_HIP, "smh_cnn_trainer_create: device allocation failed: %s", hipGetErrorString(e));
-    }
     // carve + tables
     float *ap = t->d_arena, *cp = t->d_chan;
     int2 *tp = t->d_tables;
@@ -840,10 +842,8 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
             e = hipDeviceSynchronize();
         }
     }
-    if (e != hipSuccess) {
-        smh_cnn_trainer_destroy(t);
-        return smh::set_error(SMH_E_HIP, "smh_cnn_trainer_create: setup failed: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return smh::set_error(SMH_E_HIP, "smh_cnn_trainer_create: setup failed: %s", hipGetErrorString(e));
+    guard.p = nullptr;
     *out = t;
     return SMH_OK;
 }
