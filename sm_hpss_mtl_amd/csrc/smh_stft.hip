@@ -310,18 +310,17 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         const int k = fdiv(it, inv_nf), f = it - k * nf;
         const float2 *zf = Z + f * kMP400;
         const float2 A = zf[k], Bz = zf[k == 0 ? 0 : M - k];
+        // X[k] = (e - i g) / 2 and X[M-k] = conj(e + i g) / 2 with e = A + conj(B), g = tw2[k] (A - conj(B)):
+        // one twiddle product serves both bins of the pair
+        const float2 zc = make_float2(Bz.x, -Bz.y);
+        const float2 e = cadd(A, zc), d = csub(A, zc);
+        const float2 g = cmul(tw2[k], d);
         {
-            const float2 zc = make_float2(Bz.x, -Bz.y);
-            const float2 e = cadd(A, zc), d = csub(A, zc);
-            const float2 wd = cmul(tw2[k], d);
-            const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);
+            const float re = 0.5f * (e.x + g.y), im = 0.5f * (e.y - g.x);
             Sb[(size_t)k * T + f] = __builtin_sqrtf(re * re + im * im);
         }
         if (k != M / 2) {
-            const float2 zc = make_float2(A.x, -A.y);
-            const float2 e = cadd(Bz, zc), d = csub(Bz, zc);
-            const float2 wd = cmul(tw2[M - k], d);
-            const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);
+            const float re = 0.5f * (e.x - g.y), im = 0.5f * (e.y + g.x);
             Sb[(size_t)(M - k) * T + f] = __builtin_sqrtf(re * re + im * im);
         }
     }
