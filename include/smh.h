@@ -264,6 +264,12 @@ size_t smh_cnn_workspace_bytes(const smh_cnn *m, int N);
 /* d_x (N, in_h, in_w) -> d_out (N, out_dim); d_feat (N, feat_dim) optional (null to skip) */
 int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
                         size_t work_bytes, void *stream);
+/* Mixed-precision variant ("second-priority MFMA target"): the Conv2D / Dense products take bf16
+ * operands (v_mfma_f32_32x32x16_bf16; activations rounded while they are staged, kernels from a transposed bf16 copy
+ * rebuilt after every weight change), f32 accumulation, epilogues, pooling, LRN, mel-scale layer and heads as in f32.
+ * NOT the parity path: outputs differ from smh_cnn_forward_f32 by the bf16 rounding of the operands (tests state it). */
+int smh_cnn_forward_bf16(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
+                         size_t work_bytes, void *stream);
 
 /* ---- a13 / a14: training step of the Conv2D MTL baselines (what model.fit runs per batch for the models compiled at
  * lib/proposed_architectures.py:499-506 / :572-580 / :750-757), all three kinds.  The trainer owns its activations,

@@ -98,6 +98,7 @@ SIGNATURES = {
     "smh_cnn_get_weights": (_i, [_vp, _vp, _sz, _vp]),
     "smh_cnn_workspace_bytes": (_sz, [_vp, _i]),
     "smh_cnn_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp, _sz, _vp]),
+    "smh_cnn_forward_bf16": (_i, [_vp, _fp, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_trainer_create": (_i, [_vp, _i, C.POINTER(_vp)]),
     "smh_trainer_destroy": (None, [_vp]),
     "smh_trainer_grad_ptr": (_vp, [_vp]),

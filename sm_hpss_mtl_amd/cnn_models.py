@@ -196,8 +196,11 @@ class CnnMTL(CnnTrainingMixin):
                        "smh_cnn_set_weights")
             self._dirty = False
 
-    def forward_device(self, x, out=None, features=None):
-        """x: float32 CUDA tensor (N, H, W) or (N, H, W, 1) -> (N, out_dim) [S|M|(N)|R|3C] on the device."""
+    def forward_device(self, x, out=None, features=None, dtype="f32"):
+        """x: float32 CUDA tensor (N, H, W) or (N, H, W, 1) -> (N, out_dim) [S|M|(N)|R|3C] on the device.
+        dtype="bf16": bf16 GEMM operands with f32 accumulation (smh_cnn_forward_bf16) -- faster, not the parity path."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
             raise TypeError("forward_device expects a float32 CUDA tensor")
         if x.dim() == 4 and x.shape[3] == 1:
@@ -211,10 +214,11 @@ class CnnMTL(CnnTrainingMixin):
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x.device)
         nbytes = self.lib.smh_cnn_workspace_bytes(self._h, N)
         work = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
-        _lib.check(self.lib.smh_cnn_forward_f32(
+        fn = self.lib.smh_cnn_forward_f32 if dtype == "f32" else self.lib.smh_cnn_forward_bf16
+        _lib.check(fn(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if features is None else C.c_void_p(features.data_ptr()), C.c_void_p(work.data_ptr()), work.numel(),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_cnn_forward_f32")
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_cnn_forward_" + dtype)
         return out
 
     def split_outputs(self, out):
@@ -225,11 +229,11 @@ class CnnMTL(CnnTrainingMixin):
         res.append(out[:, col:col + self.n_classes])
         return res
 
-    def predict(self, x, batch_size=None, verbose=0):
+    def predict(self, x, batch_size=None, verbose=0, dtype="f32"):
         """model.predict(x=batchData) -> [S, M, (N,) R, 3C] numpy arrays (Proposed_Work_Results.py:520,586)."""
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         elif x.dtype != torch.float32:
             x = x.float()
-        out = self.forward_device(x.cuda())
+        out = self.forward_device(x.cuda(), dtype=dtype)
         return [o.cpu().numpy() for o in self.split_outputs(out)]

@@ -45,6 +45,8 @@ extern "C" int smh_cnn_create(const smh_cnn_cfg *cfg, smh_cnn **out) {
         }
         L.es_off = m->n_fold;
         m->n_fold += 2 * (size_t)L.OC;
+        L.wbf_off = m->n_wbf;
+        m->n_wbf += (size_t)L.OC * L.Kp;
     }
     hipError_t e = hipMalloc((void **)&m->d_flat, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_fold, std::max<size_t>(m->n_fold, 1) * sizeof(float));
@@ -68,6 +70,7 @@ extern "C" void smh_cnn_destroy(smh_cnn *m) {
     (void)hipFree(m->d_fold);
     (void)hipFree(m->d_lut);
     (void)hipFree(m->d_mel);
+    (void)hipFree(m->d_wbf);
     delete m;
 }
 
@@ -115,6 +118,7 @@ extern "C" int smh_cnn_set_weights(smh_cnn *m, const float *h, size_t n, void *s
             eb[c] = (bias ? bias[c] * s : 0.f) + t;
         }
     }
+    m->wbf_valid = false;
     SMH_CHECK_HIP(hipMemcpyAsync(m->d_flat, h, n * sizeof(float), hipMemcpyHostToDevice, st));
     if (m->n_fold) SMH_CHECK_HIP(hipMemcpyAsync(m->d_fold, fold.data(), m->n_fold * sizeof(float), hipMemcpyHostToDevice, st));
     SMH_CHECK_HIP(hipStreamSynchronize(st));  // host staging buffers die here
@@ -136,8 +140,21 @@ extern "C" size_t smh_cnn_workspace_bytes(const smh_cnn *m, int N) {
     return carve(m, nullptr, N).bytes;
 }
 
+static int forward_impl(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
+                        size_t work_bytes, void *stream, bool bf16);
+
 extern "C" int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
                                    size_t work_bytes, void *stream) {
+    return forward_impl(m, d_x, N, d_out, d_feat, d_work, work_bytes, stream, false);
+}
+
+extern "C" int smh_cnn_forward_bf16(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
+                                    size_t work_bytes, void *stream) {
+    return forward_impl(m, d_x, N, d_out, d_feat, d_work, work_bytes, stream, true);
+}
+
+static int forward_impl(const smh_cnn *m, const float *d_x, int N, float *d_out, float *d_feat, void *d_work,
+                        size_t work_bytes, void *stream, bool bf16) {
     SMH_REQUIRE(m, "smh_cnn_forward_f32: null model");
     SMH_REQUIRE(N >= 0, "smh_cnn_forward_f32: negative batch");
     if (N == 0) return SMH_OK;
@@ -146,6 +163,19 @@ extern "C" int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, fl
     if (work_bytes < w.bytes)
         return smh::set_error(SMH_E_WORKSPACE, "smh_cnn_forward_f32: workspace too small (%zu < %zu bytes)", work_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (bf16 && !m->wbf_valid) {  // bf16 operand cache: every kernel transposed to [Cout][Kp], once per weight version
+        if (!m->d_wbf) SMH_CHECK_HIP(hipMalloc(&m->d_wbf, std::max<size_t>(m->n_wbf, 1) * sizeof(__bf16)));
+        for (const Layer &L : m->layers)
+            if (L.op == kConv) {
+                const size_t tot = (size_t)L.OC * L.Kp;
+                hipLaunchKernelGGL(pack_wt_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                                   (const float *)(m->d_flat + m->tensors[L.t_kernel].off), L.K, L.Kp, L.OC,
+                                   reinterpret_cast<__bf16 *>(m->d_wbf) + L.wbf_off);
+            }
+        int rcp = smh::launch_status("pack_wt_bf16_kernel");
+        if (rcp) return rcp;
+        m->wbf_valid = true;
+    }
     const size_t in_floats = (size_t)m->cfg.in_h * m->cfg.in_w;
     for (int n0 = 0; n0 < N; n0 += kChunk) {
         const int n = std::min(kChunk, N - n0);
@@ -161,15 +191,21 @@ extern "C" int smh_cnn_forward_f32(const smh_cnn *m, const float *d_x, int N, fl
                 a.H = L.H, a.W = L.W, a.Cin = L.C, a.OH = L.OH, a.OW = L.OW, a.Cout = L.OC, a.K = L.K;
                 a.M = n * L.OH * L.OW;
                 a.sh = L.sh, a.sw = L.sw, a.pt = L.pt, a.pl = L.pl, a.act = L.act;
-                a.ksteps = L.Kp / BK;
+                a.ksteps = L.Kp / (bf16 ? BKB : BK);
+                a.Kp = L.Kp;
                 a.vec4 = (L.C % 4 == 0) ? 1 : 0;
                 const int bn = L.OC <= 64 ? 64 : 128;
                 const int mt = (a.M + BM - 1) / BM, nt = (L.OC + bn - 1) / bn;
-                a.ksplit = choose_split(mt, nt, a.ksteps);
+                a.ksplit = choose_split(mt, nt, L.Kp / BK);  // the same plan for both precisions (workspace sizing)
+                if (a.ksplit > a.ksteps) a.ksplit = a.ksteps;
                 a.ksteps_per = (a.ksteps + a.ksplit - 1) / a.ksplit;
                 SMH_REQUIRE(L.OC % 4 == 0, "smh_cnn: Cout=%d is not a multiple of 4", L.OC);
                 const dim3 grid(mt, nt, a.ksplit);
-                if (bn == 64) hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, st, a);
+                if (bf16) {
+                    const __bf16 *wt = reinterpret_cast<const __bf16 *>(m->d_wbf) + L.wbf_off;
+                    if (bn == 64) hipLaunchKernelGGL(conv_gemm_bf16_kernel<64>, grid, dim3(256), 0, st, a, wt);
+                    else hipLaunchKernelGGL(conv_gemm_bf16_kernel<128>, grid, dim3(256), 0, st, a, wt);
+                } else if (bn == 64) hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, dim3(256), 0, st, a);
                 if (a.ksplit > 1) {
                     const size_t MN = (size_t)a.M * L.OC;

@@ -29,6 +29,7 @@ struct ConvArgs {
     int sh, sw, pt, pl;
     int act, ksplit, ksteps, ksteps_per;
     int vec4;
+    int Kp;  // bf16 kernel: K padded to a multiple of 32 = row length of the transposed bf16 weights
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -194,6 +195,144 @@ __global__ void splitk_epilogue_kernel(const float *__restrict__ partial, int S,
     y[i] = activate(fmaf(v, es[n], eb[n]), act);
 }
 
+// ---- mixed-precision variant: bf16 operands (v_mfma_f32_32x32x16_bf16), f32 accumulation and epilogue --------------------
+// Same implicit GEMM; activations are rounded to bf16 while the im2col gather stages them in LDS, the kernels are read
+// from a transposed bf16 copy [Cout][Kp] (k contiguous: one 16-byte load / LDS write / operand read per 8 k).
+// LDS images are [m][k] and [n][k] with 40-element rows (80 bytes: 16-byte aligned, conflict-free per 16 lanes).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+constexpr int BKB = 32, BKP = 40;
+
+template <int BN>
+__global__ void __launch_bounds__(256) conv_gemm_bf16_kernel(ConvArgs a, const __bf16 *__restrict__ wt) {
+    constexpr int NT = BN / 64;
+    constexpr int NBC = BN * 4 / 256;  // 16-byte B chunks per thread and k tile
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN][BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    const int p = tid & (BM - 1);
+    const int m = m0 + p;
+    const bool valid_m = m < a.M;
+    int iy0 = 0, ix0 = 0;
+    long base = 0;
+    if (valid_m) {
+        const int ohw = a.OH * a.OW;
+        const int img = m / ohw, r = m - img * ohw;
+        const int oy = r / a.OW, ox = r - oy * a.OW;
+        iy0 = oy * a.sh - a.pt;
+        ix0 = ox * a.sw - a.pl;
+        base = (((long)img * a.H + iy0) * a.W + ix0) * a.Cin;
+    }
+    const int kq0 = tid >> 7;  // wave-uniform
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4];
+    bf16x8 rb[NBC];
+    auto gload = [&](int ks) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = __builtin_amdgcn_readfirstlane(ks * BKB + 4 * (kq0 + 2 * it));
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.vec4) {
+                const int2 e = a.lut[k];
+                const int iy = iy0 + (short)(e.y & 0xffff), ix = ix0 + (e.y >> 16);
+                if (valid_m && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = *reinterpret_cast<const f32x4 *>(a.x + base + e.x);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int2 e = a.lut[k + q];
+                    const int iy = iy0 + (short)(e.y & 0xffff), ix = ix0 + (e.y >> 16);
+                    if (valid_m && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v[q] = a.x[base + e.x];
+                }
+            }
+            ra[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NBC; ++it) {
+            const int idx = tid + it * 256;
+            const int n = idx >> 2, k8 = idx & 3;
+            bf16x8 v;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (__bf16)0.0f;
+            if (n0 + n < a.Cout) v = *reinterpret_cast<const bf16x8 *>(wt + (size_t)(n0 + n) * a.Kp + ks * BKB + k8 * 8);
+            rb[it] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const bf16x4 v = {(__bf16)ra[it][0], (__bf16)ra[it][1], (__bf16)ra[it][2], (__bf16)ra[it][3]};
+            *reinterpret_cast<bf16x4 *>(&As[buf][p][4 * (kq0 + 2 * it)]) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NBC; ++it) {
+            const int idx = tid + it * 256;
+            *reinterpret_cast<bf16x8 *>(&Bs[buf][idx >> 2][(idx & 3) * 8]) = rb[it];
+        }
+    };
+    const int ks_begin = z * a.ksteps_per;
+    const int ks_end = min(a.ksteps, ks_begin + a.ksteps_per);
+    if (ks_begin < ks_end) {
+        gload(ks_begin);
+        sstore(0);
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int cur = (ks - ks_begin) & 1;
+            const bool more = ks + 1 < ks_end;
+            if (more) gload(ks + 1);
+#pragma unroll
+            for (int kk = 0; kk < BKB / 16; ++kk) {
+                const int ko = kk * 16 + 8 * (lane >> 5);
+                bf16x8 av[2], bv[NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * 64 + i * 32 + (lane & 31)][ko]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * (BN / 2) + j * 32 + (lane & 31)][ko]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) sstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            if (n >= a.Cout) continue;
+            const float es = a.ksplit == 1 ? a.es[n] : 1.f, eb = a.ksplit == 1 ? a.eb[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (mm >= a.M) continue;
+                const float v = acc[i][j][r];
+                if (a.ksplit > 1) a.partial[((size_t)z * a.M + mm) * a.Cout + n] = v;
+                else a.y[(size_t)mm * a.Cout + n] = activate(fmaf(v, es, eb), a.act);
+            }
+        }
+}
+
+// wt[n][k] = bf16(w[k][n]) for k < K, 0 up to Kp: one thread per element
+__global__ void pack_wt_bf16_kernel(const float *__restrict__ w, int K, int Kp, int Cout, __bf16 *__restrict__ wt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Cout * Kp) return;
+    const int k = (int)(i % Kp);
+    const size_t n = i / Kp;
+    wt[i] = (__bf16)(k < K ? w[(size_t)k * Cout + n] : 0.f);
+}
+
 // MaxPooling2D, NHWC, 'valid' or 'same' (pt/pl = top/left padding; out-of-image taps are skipped = -inf padding)
 __global__ void maxpool_kernel(const float *__restrict__ x, int H, int W, int C, int OH, int OW, int ph, int pw, int sh,
                                int sw, int pt, int pl, size_t total, float *__restrict__ y) {
@@ -355,6 +494,7 @@ struct Layer {
     size_t es_off = 0;                   // folded scale/shift in d_fold
     int K = 0, Kp = 0;
     size_t lut_off = 0;
+    size_t wbf_off = 0;                  // this layer's transposed bf16 kernel [OC][Kp] in d_wbf (bf16 elements)
     float drop = 0.f;                    // Dropout rate behind this layer's activation (training only)
     int l2 = 0;                          // kernel_regularizer=l2() on this layer's kernel (Jang)
 };
@@ -375,6 +515,10 @@ struct smh_cnn {
     size_t n_fold = 0;
     int mel_rows = 0, mel_in_rows = 0;
     int c3_l2 = 0;             // Jang: l2() on the '3C' kernel too (proposed_architectures.py:747)
+    // bf16 operand cache of smh_cnn_forward_bf16: every Conv2D / Dense kernel transposed to [Cout][Kp], rebuilt lazily
+    mutable void *d_wbf = nullptr;
+    mutable bool wbf_valid = false;
+    size_t n_wbf = 0;
     std::vector<float> h_flat;
 };
 
@@ -427,7 +571,7 @@ void push_conv(smh_cnn *m, Cur &c, const std::string &name, int kh, int kw, int 
     if (bias) L.t_bias = add_tensor(m, name + "/bias", {oc});
     if (!bn.empty()) L.t_bn = add_bn(m, bn, oc);
     L.K = kh * kw * c.C;
-    L.Kp = (L.K + BK - 1) / BK * BK;
+    L.Kp = (L.K + 31) / 32 * 32;  // a multiple of both k tiles (16 for the f32 kernel, 32 for the bf16 one)
     L.drop = drop, L.l2 = l2;
     m->layers.push_back(L);
     c.H = L.OH, c.W = L.OW, c.C = oc;
@@ -441,7 +585,7 @@ void push_dense(smh_cnn *m, Cur &c, const std::string &name, int oc, int act, co
     L.t_bias = add_tensor(m, name + "/bias", {oc});
     if (!bn.empty()) L.t_bn = add_bn(m, bn, oc);
     L.K = L.C;
-    L.Kp = (L.K + BK - 1) / BK * BK;
+    L.Kp = (L.K + 31) / 32 * 32;
     L.drop = drop, L.l2 = l2;
     m->layers.push_back(L);
     c.H = c.W = 1, c.C = oc;

@@ -1113,6 +1113,7 @@ extern "C" int smh_cnn_trainer_apply_f32(smh_cnn_trainer *t, int optimizer, floa
     smh_cnn *m = t->m;
     hipStream_t st = (hipStream_t)stream;
     t->step += 1;
+    m->wbf_valid = false;  // the bf16 operand cache of smh_cnn_forward_bf16 follows the weights
     OptArgs o{};
     o.optimizer = optimizer, o.lr = lr, o.b1 = beta1, o.b2 = beta2, o.eps = eps, o.grad_scale = grad_scale;
     if (optimizer == 1)

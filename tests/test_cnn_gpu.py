@@ -103,3 +103,32 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         m.set_weights(m.get_weights()[:-1])
     assert m.forward_device(torch.zeros((0, 40, 68), device="cuda")).shape == (0, 7)
+
+
+@pytest.mark.parametrize("kind,H,W,N,fc", [("Doukhan", 240, 68, 70, 0), ("Doukhan", 40, 68, 3, 0), ("Papakostas", 402, 68, 3, 128),
+                                           ("Jang", 514, 20, 3, 0)])
+def test_bf16_operand_variant(kind, H, W, N, fc):
+    """smh_cnn_forward_bf16: bf16 GEMM operands (activations and kernels rounded to 8 mantissa bits), f32 accumulation.
+    Not the parity path -- the distance to the f32 path is what operand rounding through 6-9 layers gives: features
+    within 3 % of their largest entry, outputs within 5e-2, and the cache follows weight changes."""
+    w, _ = _oracle(kind, H, W, 3, fc or 64)
+    m = _model(kind, H, W, 3, fc_width=fc)
+    m.set_weights_dict(w)
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((N, H, W)).astype(np.float32)).cuda()
+    f32f, bff = torch.empty((N, m.feat_dim), device="cuda"), torch.empty((N, m.feat_dim), device="cuda")
+    o32 = m.forward_device(x, features=f32f).cpu().numpy()
+    o16 = m.forward_device(x, features=bff, dtype="bf16").cpu().numpy()
+    fe32, fe16 = f32f.cpu().numpy(), bff.cpu().numpy()
+    assert np.isfinite(o16).all()
+    ferr = np.abs(fe16 - fe32).max() / max(np.abs(fe32).max(), 1e-6)
+    oerr = np.abs(o16 - o32).max()
+    print("%s %dx%d: bf16 vs f32 features %.2e of max, outputs %.2e" % (kind, H, W, ferr, oerr))
+    assert 0 < ferr < 3e-2 and oerr < 5e-2
+    # the operand cache is rebuilt when the weights change
+    w2 = {k: (v * 0.5 if k == "conv1/kernel" else v) for k, v in w.items()}
+    m.set_weights_dict(w2)
+    o16b = m.forward_device(x, dtype="bf16").cpu().numpy()
+    o32b = m.forward_device(x).cpu().numpy()
+    assert np.abs(o16b - o32b).max() < 5e-2 and np.abs(o32b - o32).max() > 0
+    with pytest.raises(ValueError):
+        m.forward_device(x, dtype="fp8")

@@ -11,19 +11,21 @@ for kind, shape in (("Doukhan", (240, 68, 1)), ("Jang", (514, 68, 1)), ("Papakos
         continue
     m = CnnMTL(kind, shape, seed=0)
     x = torch.randn((N,) + shape[:2], device="cuda")
-    for _ in range(2):
-        m.forward_device(x)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    K = 5
-    e0.record()
-    for _ in range(K):
-        m.forward_device(x)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / K
-    r = {"model": kind, "N": N, "ms": round(ms, 3), "patches_per_s": round(N / ms * 1e3)}
-    if FLOPS[kind]:
-        r["TFLOPs"] = round(FLOPS[kind] * N / ms / 1e9, 2)
-        r["frac_f32_mfma_peak"] = round(FLOPS[kind] * N / ms / 1e9 / 157.3, 3)
-    print(json.dumps(r), flush=True)
+    for dtype in ("f32", "bf16"):
+        for _ in range(2):
+            m.forward_device(x, dtype=dtype)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K = 5
+        e0.record()
+        for _ in range(K):
+            m.forward_device(x, dtype=dtype)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        r = {"model": kind, "dtype": dtype, "N": N, "ms": round(ms, 3), "patches_per_s": round(N / ms * 1e3)}
+        if FLOPS[kind]:
+            r["TFLOPs"] = round(FLOPS[kind] * N / ms / 1e9, 2)
+            if dtype == "f32":
+                r["frac_f32_mfma_peak"] = round(FLOPS[kind] * N / ms / 1e9 / 157.3, 3)
+        print(json.dumps(r), flush=True)
