@@ -116,6 +116,15 @@ def test_adam_update_and_moving_statistics():
     ref_outs = cnn_mtl.forward_doukhan(x[..., None], {k: v.astype(np.float32) for k, v in w.items()})
     for o, r in zip(outs, ref_outs):
         np.testing.assert_allclose(o, r, atol=2e-4)
+    # ... and the bf16 operand cache follows the optimiser's updates too
+    old32 = m.predict(x)
+    m.predict(x, dtype="bf16")          # builds the cache from the current weights
+    m.initial_learning_rate = 0.02      # a step large enough to move the outputs visibly
+    m.train_on_batch(*_batch(N, H, W, 77), drop=None, drop_heads=None)
+    new32, new16 = m.predict(x), m.predict(x, dtype="bf16")
+    assert max(np.abs(a - b).max() for a, b in zip(new32, old32)) > 0.2  # a stale cache would reproduce the old outputs
+    for o16, o32 in zip(new16, new32):
+        np.testing.assert_allclose(o16, o32, atol=5e-2)
 
 
 def _papakostas(H, W, fc, seed=4):
