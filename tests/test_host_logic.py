@@ -46,7 +46,7 @@ def test_integer_contracts_match_oracle(golden_fe):
 def test_product_never_imports_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[/.]_ref|libsmh_oracle", re.M)
-    for base in ("sm_hpss_mtl_amd", "lib"):
+    for base in ("sm_hpss_mtl_amd", "lib", "tools"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
                 if f.endswith((".py", ".hip", ".h", ".cpp")):
