@@ -322,3 +322,41 @@ def test_trainer_c_abi_errors():
     finally:
         lib.smh_cnn_trainer_destroy(h)
     lib.smh_cnn_trainer_destroy(None)  # no-op
+
+
+def _cnn_dp_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the test box: gloo carries the CUDA tensor
+    m, _ = _model(30, 68, seed=13)
+    x, y = _batch(8, 30, 68, 21)
+    sl = slice(rank * 4, rank * 4 + 4)
+    for _ in range(2):
+        m.train_on_batch(x[sl], {k: v[sl] for k, v in y.items()}, drop=None, drop_heads=None)
+    got = m.get_weights_dict()
+    q.put((rank, {k: got[k].copy() for k in ("conv2/kernel", "bn3/gamma", "fc1/kernel", "3C/kernel", "S/out/kernel")}))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_allreduce_two_ranks():
+    """SURVEY 8e for the Conv2D trainer: one all-reduce of the flat gradient per step; replicas stay bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import cnn_mtl
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cnn_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=300) for _ in range(2))
+    [p.join(120) for p in ps]
+    w0 = cnn_mtl.init_doukhan(seed=13, H=30, W=68)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k          # replicas agree exactly
+        assert not np.array_equal(res[0][k], w0[k]), k          # and the weights moved
