@@ -211,6 +211,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
 
 struct BwdArgs {
     int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
+    int use_wt;  // VALU kernel: keep transposed LDS copies of the block kernels (0 for patches so long that they do not fit)
     Offsets off;
 };
 
@@ -228,9 +229,10 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
     float *W2 = W1 + 3 * C * C;             // [32][32]
     // transposed copies for the two phases whose lanes run over the INPUT channel: W1T[tap][co][c], W2T[co][c]
     // (reading W[c*32 + co] with 32 lanes over c is a 32-way LDS bank conflict: it was 60 % of the kernel's time)
+    // (patches of more than ~200 frames leave no room for them: use_wt = 0 reads W1 / W2 transposed, conflicts and all)
     float *W1T = W2 + C * C;                // [3][32][32]
     float *W2T = W1T + 3 * C * C;           // [32][32]
-    float *B1 = W2T + C * C;                // [32]
+    float *B1 = a.use_wt ? W2T + C * C : W2 + C * C;  // [32]
     float *rowm = B1 + C;                   // per row: m
     float *rowmx = rowm + RP;               // per row: max
     float *dps = rowmx + RP;                // [kBG][kPS] d loss / d pre
@@ -278,12 +280,12 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
             const float v = flatw[o_k1 + i];
             W1[i] = v;
             const int tap = i / (C * C), c = (i / C) % C, co = i % C;
-            W1T[(tap * C + co) * C + c] = v;
+            if (a.use_wt) W1T[(tap * C + co) * C + c] = v;
         }
         for (int i = tid; i < C * C; i += nt) {
             const float v = flatw[o_k2 + i];
             W2[i] = v;
-            W2T[(i % C) * C + i / C] = v;
+            if (a.use_wt) W2T[(i % C) * C + i / C] = v;
         }
         if (tid < C) B1[tid] = flatw[o_b1 + tid];
         __syncthreads();
@@ -332,10 +334,11 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
         for (int i = tid; i < rows * C; i += nt) {
             const int R = i / C, c = i - R * C;
             const float *gr = G + R * kBS;
-            const float *w = W2T + c;
+            const float *w = a.use_wt ? W2T + c : W2 + c * C;  // element (co, c) of W2^T
+            const int ws = a.use_wt ? C : 1;
             float dyn = 0.f;
 #pragma unroll 8
-            for (int co = 0; co < C; ++co) dyn = fmaf(gr[co], w[co * C], dyn);
+            for (int co = 0; co < C; ++co) dyn = fmaf(gr[co], w[co * ws], dyn);
             const float mask = drop ? drop[((size_t)(n0 + R / T) * a.n_blocks + blk) * C + c] : 1.0f;
             dyn *= mask;
             const float u = U[R * kBS + c];
@@ -376,9 +379,10 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
                 const int off = (tap - 1) * d;
                 if (t - off < 0 || t - off >= T) continue;
                 const float *dur = U + (R - off) * kBS;
-                const float *w = W1T + tap * C * C + c;
+                const float *w = a.use_wt ? W1T + tap * C * C + c : W1 + (tap * C + c) * C;
+                const int ws = a.use_wt ? C : 1;
 #pragma unroll 8
-                for (int co = 0; co < C; ++co) acc = fmaf(dur[co], w[co * C], acc);
+                for (int co = 0; co < C; ++co) acc = fmaf(dur[co], w[co * ws], acc);
             }
             G[R * kBS + c] = acc;
         }
@@ -416,6 +420,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMG = 1;
 constexpr int kMThreads = 512;
+constexpr int kMfmaMaxT = 128;  // two float4 of saved activations per thread in the register prefetch
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -492,7 +497,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     };
 
     // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
-    constexpr int kPfX = (kMG * 80 * (C / 4) + kMThreads - 1) / kMThreads;  // T <= 80 per patch (checked on the host)
+    constexpr int kPfX = (kMG * kMfmaMaxT * (C / 4) + kMThreads - 1) / kMThreads;  // T <= kMfmaMaxT per patch (checked on the host)
     f32x4 pf_x[kPfX];
     float pf_w1[6], pf_w2[2], pf_b1 = 0.f;
     auto prefetch = [&](int blk) {
@@ -885,6 +890,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (rc) return rc;
     BwdArgs ba;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
+    ba.use_wt = 1;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
     hipLaunchKernelGGL(l2_penalty_kernel, dim3(1), dim3(1024), 0, st, ba, m->d_flat, d_losses + m->n_heads + 3);
     rc = smh::launch_status("l2_penalty_kernel");
@@ -892,7 +898,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
     const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 2 * 3 * C * C + C * C + C + kMG * kPS);
-    if (lds_m <= 156 * 1024 && ba.T <= 80 && !getenv("SMH_TRAIN_VALU")) {
+    if (lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT && !getenv("SMH_TRAIN_VALU")) {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         hipLaunchKernelGGL(tcn_backward_mfma_kernel, dim3((N + kMG - 1) / kMG), dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat,
                            t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad, RPm);
@@ -903,8 +909,13 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
         return smh::launch_status("dwh_kernel");
     }
     const int RP = kBG * ba.T;
-    const size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);
-    SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel", ba.T);
+    size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);
+    ba.use_wt = 1;
+    if (lds > 156 * 1024) {  // long patches (the reference's W = 249): no room for the transposed kernel copies
+        ba.use_wt = 0;
+        lds -= sizeof(float) * (3 * C * C + C * C);
+    }
+    SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the backward kernel (at most 264 frames)", ba.T);
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tcn_backward_kernel, dim3((N + kBG - 1) / kBG), dim3(kBThreads), lds, st, ba, d_x, m->d_flat,
                        t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad);

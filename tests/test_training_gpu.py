@@ -31,12 +31,14 @@ def _flat_to_dict(model, flat):
     return out
 
 
-@pytest.mark.parametrize("ncls,N", [(3, 6), (5, 5), (3, 1)])
-def test_gradients_and_losses_vs_oracle(ncls, N):
+@pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68),
+                                      (3, 3, 99),    # DAFx12...:760 -- longer than the MFMA backward covers: scalar kernel
+                                      (3, 2, 249)])  # Proposed_Work_Results.py:724 -- scalar kernel without the transposed LDS copies
+def test_gradients_and_losses_vs_oracle(ncls, N, W):
     from sm_hpss_mtl_amd.model import B3MTL
-    w, x, y, drop_tcn, drop_heads = _problem(ncls, N)
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, W=W)
     lw = {"S": 0.7, "R": 1.3}
-    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls, loss_weights=lw)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls, loss_weights=lw)
     m.set_weights_dict(w)
     heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
     got = m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda(),
