@@ -420,16 +420,22 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMG = 1;
 constexpr int kMThreads = 512;
-constexpr int kMfmaMaxT = 128;  // two float4 of saved activations per thread in the register prefetch
+constexpr int kMfmaMaxT = 128;   // two float4 of saved activations per thread in the register prefetch
+constexpr int kMfmaLongT = 256;  // four; kernels read from global memory (no LDS left)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// WLDS: the block's kernels (canonical, and transposed for the products whose k runs over the output channel) are
+// parked in LDS.  Patches longer than 128 frames (the reference's W = 249) leave no room for them next to the four
+// activation images: WLDS = false reads the canonical kernel and the bias from the weight vector itself and the
+// transposed copies from `wtr` ([block][W1T 3*32*32 | W2T 32*32], written by transpose_block_weights_kernel per step).
+template <bool WLDS, int MAXT>
 __global__ void __launch_bounds__(kMThreads)
 tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw,
                          const float *__restrict__ acts, const float *__restrict__ drop, const float *__restrict__ dpre,
-                         float *__restrict__ grad, int RPm) {
+                         float *__restrict__ grad, int RPm, const float *__restrict__ wtr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int T = a.T, nslot = a.n_blocks + 1;
     const int n0 = blockIdx.x * kMG;
@@ -441,7 +447,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     float *W1T = W1 + 3 * C * C;        // [3][32 cout][32 cin]
     float *W2T = W1T + 3 * C * C;       // [32 cout][32 cin]
     float *B1 = W2T + C * C;            // [32]
-    float *dps = B1 + C;                // [kMG][kPS]
+    float *dps = WLDS ? B1 + C : Y + (size_t)RPm * SX;  // [kMG][kPS]
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int q = lane >> 4, j = lane & 15;
@@ -497,7 +503,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     };
 
     // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
-    constexpr int kPfX = (kMG * kMfmaMaxT * (C / 4) + kMThreads - 1) / kMThreads;  // T <= kMfmaMaxT per patch (checked on the host)
+    constexpr int kPfX = (kMG * MAXT * (C / 4) + kMThreads - 1) / kMThreads;  // T <= MAXT per patch (checked on the host)
     f32x4 pf_x[kPfX];
     float pf_w1[6], pf_w2[2], pf_b1 = 0.f;
     auto prefetch = [&](int blk) {
@@ -511,11 +517,13 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 pf_x[e] = *reinterpret_cast<const f32x4 *>(acts + (((size_t)(n0 + g) * nslot + blk) * T + t) * C + c4);
             }
         }
+        if (WLDS) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) pf_w1[e] = flatw[wo + tid + e * kMThreads];
+            for (int e = 0; e < 6; ++e) pf_w1[e] = flatw[wo + tid + e * kMThreads];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) pf_w2[e] = flatw[wo + 3 * C * C + C + tid + e * kMThreads];
-        if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
+            for (int e = 0; e < 2; ++e) pf_w2[e] = flatw[wo + 3 * C * C + C + tid + e * kMThreads];
+            if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
+        }
     };
     prefetch(a.n_blocks - 1);
     // ---- residual blocks, last to first --------------------------------------------------------------------------
@@ -530,19 +538,23 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             const int i = tid + e * kMThreads;
             if (i < rows * (C / 4)) *reinterpret_cast<f32x4 *>(Xs + (size_t)(i >> 3) * SX + (i & 7) * 4) = pf_x[e];
         }
+        if (WLDS) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int i = tid + e * kMThreads;  // 3*C*C = 6 * 512
-            W1[i] = pf_w1[e];
-            const int tap = i / (C * C), c = (i / C) % C, co = i % C;
-            W1T[(tap * C + co) * C + c] = pf_w1[e];
-        }
+            for (int e = 0; e < 6; ++e) {
+                const int i = tid + e * kMThreads;  // 3*C*C = 6 * 512
+                W1[i] = pf_w1[e];
+                const int tap = i / (C * C), c = (i / C) % C, co = i % C;
+                W1T[(tap * C + co) * C + c] = pf_w1[e];
+            }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int i = tid + e * kMThreads;  // C*C = 2 * 512
-            W2T[(i % C) * C + i / C] = pf_w2[e];
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * kMThreads;  // C*C = 2 * 512
+                W2T[(i % C) * C + i / C] = pf_w2[e];
+            }
+            if (tid < C) B1[tid] = pf_b1;
         }
-        if (tid < C) B1[tid] = pf_b1;
+        const float *W1p = WLDS ? W1 : flatw + o_k1, *B1p = WLDS ? B1 : flatw + o_b1;
+        const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2Tp = WLDS ? W2T : wtr + (size_t)blk * 4 * C * C + 3 * C * C;
         __syncthreads();
         if (blk > 0) prefetch(blk - 1);  // overlaps with the three phases below
         // ---- phase 1: recompute, norm, dyn, norm backward -> Y, DU ---------------------------------------------
@@ -551,14 +563,14 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             const bool live = R < rows;
             const int Rc = min(R, rows - 1);
             const int t = Rc % T;
-            f32x4 acc0 = *reinterpret_cast<const f32x4 *>(B1 + 4 * q), acc1 = *reinterpret_cast<const f32x4 *>(B1 + 16 + 4 * q);
+            f32x4 acc0 = *reinterpret_cast<const f32x4 *>(B1p + 4 * q), acc1 = *reinterpret_cast<const f32x4 *>(B1p + 16 + 4 * q);
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int off = (tap - 1) * d;
                 const bool ok = (t + off >= 0) && (t + off < T);
                 if (tap != 1 && !__any(ok)) continue;
                 const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + q;
-                const float *wa = W1 + (size_t)(tap * C + q) * C + j;  // W1[tap][cin = 4 s8 + q][cout = j (+16)]
+                const float *wa = W1p + (size_t)(tap * C + q) * C + j;  // W1[tap][cin = 4 s8 + q][cout = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     float bv = src[4 * s8];
@@ -594,7 +606,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             {
                 const float *gs = G + (size_t)Rc * SX + q;
-                const float *wa = W2T + (size_t)q * C + j;  // W2T[co = 4 s + q][c = j (+16)]
+                const float *wa = W2Tp + (size_t)q * C + j;  // W2T[co = 4 s + q][c = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const float bv = live ? gs[4 * s8] : 0.f;
@@ -655,7 +667,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const bool ok = (t - off >= 0) && (t - off < T);
                 if (tap != 1 && !__any(ok)) continue;
                 const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + q;
-                const float *wa = W1T + (size_t)(tap * C + q) * C + j;  // W1T[tap][co = 4 s8 + q][c = j (+16)]
+                const float *wa = W1Tp + (size_t)(tap * C + q) * C + j;  // W1T[tap][co = 4 s8 + q][c = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     float bv = src[4 * s8];
@@ -694,6 +706,18 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             }
         }
     }
+}
+
+// wtr[blk] = [W1T[tap][co][c] | W2T[co][c]] from the canonical block kernels (long-patch variant of the kernel above)
+__global__ void transpose_block_weights_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ wtr) {
+    const int blk = blockIdx.x;
+    const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+    float *dst = wtr + (size_t)blk * 4 * C * C;
+    for (int i = threadIdx.x; i < 3 * C * C; i += blockDim.x) {
+        const int tap = i / (C * C), c = (i / C) % C, co = i % C;
+        dst[(tap * C + co) * C + c] = flatw[wo + i];
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) dst[3 * C * C + (i % C) * C + i / C] = flatw[wo + 3 * C * C + C + i];
 }
 
 // dWh[k][o] = sum_b relu(x_b)[k] dpre[b][o] for the '3C' kernel (grid.z = 0) and the Dense(16) kernel of every head
@@ -794,7 +818,7 @@ struct smh_trainer {
     smh_model *m;
     int max_batch, nseg;
     float *d_acts = nullptr, *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr, *d_grad = nullptr, *d_vel = nullptr;
-    float *d_bnstat = nullptr, *d_sumsq = nullptr, *d_scratch_out = nullptr;
+    float *d_bnstat = nullptr, *d_sumsq = nullptr, *d_scratch_out = nullptr, *d_wtr = nullptr;
     Segment *d_segs = nullptr;
 };
 
@@ -838,6 +862,7 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_bnstat, kMaxHeads * 32 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_sumsq, segs.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_scratch_out, (size_t)max_batch * m->out_dim * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_wtr, (size_t)m->n_blocks * 4 * C * C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Segment));
     if (e == hipSuccess) e = hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(t->d_vel, 0, m->n_params * sizeof(float));
@@ -852,7 +877,7 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
 
 extern "C" void smh_trainer_destroy(smh_trainer *t) {
     if (!t) return;
-    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_bnstat, t->d_sumsq, t->d_scratch_out})
+    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_bnstat, t->d_sumsq, t->d_scratch_out, t->d_wtr})
         (void)hipFree(p);
     (void)hipFree(t->d_segs);
     delete t;
@@ -898,10 +923,22 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
     const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 2 * 3 * C * C + C * C + C + kMG * kPS);
-    if (lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT && !getenv("SMH_TRAIN_VALU")) {
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        hipLaunchKernelGGL(tcn_backward_mfma_kernel, dim3((N + kMG - 1) / kMG), dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat,
-                           t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad, RPm);
+    const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS);  // kernels stay in global memory
+    const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
+    if ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU")) {
+        const dim3 grid((N + kMG - 1) / kMG);
+        if (short_ok) {
+            auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+            hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,
+                               RPm, (const float *)nullptr);
+        } else {
+            hipLaunchKernelGGL(transpose_block_weights_kernel, dim3(m->n_blocks), dim3(256), 0, st, ba, (const float *)m->d_flat, t->d_wtr);
+            auto kern = tcn_backward_mfma_kernel<false, kMfmaLongT>;
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
+            hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_long, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre,
+                               t->d_grad, RPm, (const float *)t->d_wtr);
+        }
         rc = smh::launch_status("tcn_backward_mfma_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(dwh_kernel, dim3((ba.D * kHidden + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice, 1 + ba.n_heads),

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step (a multiple of 3)")
     ap.add_argument("--classes", type=int, default=3, choices=[3, 5])
+    ap.add_argument("--patch", type=int, default=68, help="patch width W (68; the reference's drivers also use 99 and 249)")
+    ap.add_argument("--shift", type=int, default=0, help="patch shift (default: W, 24 for W = 249 as in Proposed_Work_Results.py:724-725)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     torch.cuda.set_device(local_rank)
@@ -40,20 +42,25 @@ def main():
     groups = 3 if args.classes == 3 else 5
     bs = args.batch // groups
     B = bs * groups
+    W = args.patch
+    shift = args.shift or (24 if W == 249 else W)
     fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
-    model = B3MTL(n_feat=240, patch_size=68, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
+    model = B3MTL(n_feat=240, patch_size=W, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
     audio = torch.from_numpy(np.tile(synth_clips(64, seed=2000 + rank), ((B + 63) // 64, 1))[:B]).cuda()
     smr = np.array([(-5, 0, 5, 10, 15, 20)[i % 6] for i in range(bs)], np.float64)
     lab = make_labels_3class(bs, smr) if args.classes == 3 else make_labels_5class(bs, smr, smr[::-1].copy())
+    nP = fe.num_patches(fe.num_frames(audio.shape[1]), W, shift)  # short clips are tiled along time first (preprocessing.py:139-142)
+    assert nP >= 1
+    lab = {k: np.repeat(v, nP, axis=0) for k, v in lab.items()}
     y = model.pack_targets(lab)
-    assert y.shape[0] == B, (y.shape, B)
+    assert y.shape[0] == B * nP, (y.shape, B, nP)
     out = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
     def step(timed=False):
         if timed:
             ev[0].record()
-        res = fe.run(audio, W=68, shift=68, out=out)
+        res = fe.run(audio, W=W, shift=shift, out=out)
         out.update(fv=res["fv"], patches=res["patches"])
         x = res["patches"]
         x = x + 1e-5 * torch.randn_like(x)  # noise_augmentation (Proposed_Work_Results.py:239-242)
@@ -87,8 +94,8 @@ def main():
             "metric": "clips/sec HPSS + B3_MTL training step (1s@16kHz)", "value": round(world * B * args.steps / dt, 1),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "dtype": "f32",
-            "data": "synthetic", "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=68 patches -> B3_MTL(%d-class) "
-                                            "train step, SGD(momentum 0.9, clipnorm 1)" % (B, args.classes),
+            "data": "synthetic", "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=%d patches (%d per clip) -> B3_MTL(%d-class) "
+                                            "train step, SGD(momentum 0.9, clipnorm 1)" % (B, W, nP, args.classes),
                                             "gradient_allreduce_bytes": 4 * model.count_params() if world > 1 else 0},
             "stages_ms": {"front_end_and_augmentation": round(ev[0].elapsed_time(ev[1]), 4),
                           "train_step_incl_allreduce_and_host_sync": round(ev[1].elapsed_time(ev[2]), 4)},
