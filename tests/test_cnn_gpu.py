@@ -47,7 +47,8 @@ def _check(kind, H, W, N, n_classes=3, fc=64, feat_tol=2e-4):
     return m
 
 
-@pytest.mark.parametrize("H,W,N", [(40, 68, 3), (240, 68, 2), (64, 80, 5)])
+@pytest.mark.parametrize("H,W,N", [(40, 68, 3), (240, 68, 2), (64, 80, 5),
+                                   (240, 249, 2)])  # the input of Proposed_Work_Results.py (W = 249): flatten 56 320
 def test_doukhan_vs_oracle(H, W, N):
     _check("Doukhan", H, W, N)
 

@@ -244,6 +244,22 @@ def test_jang_train_step_matches_autograd(W, N, dropout):
         assert np.abs(new[k].astype(np.float64) - v).max() <= tol, k
 
 
+def test_train_step_at_the_drivers_patch_width():
+    """(240, 249, 1) images as Proposed_Work_Results.py:794-796 feeds them: losses against the oracle, gradients in direction."""
+    from oracle import cnn_mtl_train
+    H, W, N = 240, 249, 4
+    m, w = _model(H, W)
+    x, y = _batch(N, H, W, 4)
+    ref = cnn_mtl_train.forward_backward(x, y, w)
+    res = dict(zip(m.metrics_names, m.train_on_batch(x, y, drop=None, drop_heads=None, apply=False)))
+    for k in ("S", "M", "R", "3C"):
+        assert res[k + "_loss"] == pytest.approx(ref["losses"][k], rel=2e-4, abs=2e-5), k
+    got = m.gradients()
+    for name in ("conv1/kernel", "conv4/kernel", "fc1/kernel", "bn2/gamma", "3C/kernel"):
+        a, b = got[name].astype(np.float64).ravel(), ref["grads"][name].ravel()
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.9995, name
+
+
 def test_fit_reduces_the_loss():
     from sm_hpss_mtl_amd.cnn_models import CnnMTL
     H, W, N = 30, 68, 12
