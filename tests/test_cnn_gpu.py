@@ -53,12 +53,12 @@ def test_doukhan_vs_oracle(H, W, N):
     _check("Doukhan", H, W, N)
 
 
-@pytest.mark.parametrize("H,W,N,fc", [(66, 40, 3, 64), (402, 68, 2, 128)])
+@pytest.mark.parametrize("H,W,N,fc", [(66, 40, 3, 64), (402, 68, 2, 128), (402, 249, 1, 64)])  # the last: the driver's input
 def test_papakostas_vs_oracle(H, W, N, fc):
     _check("Papakostas", H, W, N, fc=fc)
 
 
-@pytest.mark.parametrize("W,N", [(12, 3), (68, 2)])
+@pytest.mark.parametrize("W,N", [(12, 3), (68, 2), (249, 1)])  # 249: the driver's input (Proposed_Work_Results.py:795)
 def test_jang_vs_oracle(W, N):
     _check("Jang", 514, W, N)
 
