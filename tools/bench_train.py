@@ -63,7 +63,7 @@ def main():
         res = fe.run(audio, W=W, shift=shift, out=out)
         out.update(fv=res["fv"], patches=res["patches"])
         x = res["patches"]
-        x = x + 1e-5 * torch.randn_like(x)  # noise_augmentation (Proposed_Work_Results.py:239-242)
+        x = x + 1e-3 * torch.randn_like(x)  # noise_augmentation (Proposed_Work_Results.py:239-242; scale drawn from {5e-3, 1e-3, 5e-4, 1e-4} there)
         if timed:
             ev[1].record()
         r = model.train_on_batch(x, y)  # includes the gradient all-reduce and the optimiser step
