@@ -52,11 +52,38 @@ def medfilt(x, kernel_size):
     return y.cpu().numpy() if was_np else y
 
 
+def mode_filtering(X, win_size):
+    """DAFx12...:81-89 (host code, label post-processing): the most frequent label of the window
+    X[i - h : i + h], h = odd(win_size) // 2 -- note the window holds 2h elements, the element at i + h is not in it --
+    the smallest label on a tie (np.unique sorts), the first and last h entries kept as they are."""
+    X = np.asarray(X)
+    if win_size % 2 == 0:
+        win_size += 1
+    h = int(win_size / 2)
+    out = X.copy()
+    n = len(X)
+    if h == 0 or n <= 2 * h:
+        return out
+    labels = np.unique(X)
+    # counts of every label in the window by prefix sums: window of i covers [i - h, i + h)
+    best = np.full(n - 2 * h, -1, np.int64)
+    arg = np.zeros(n - 2 * h, X.dtype)
+    for lab in labels:  # ascending: a later label only wins with a strictly larger count
+        cs = np.concatenate([[0], np.cumsum(X == lab)])
+        cnt = cs[2 * h:n] - cs[0:n - 2 * h]
+        win = cnt > best
+        best = np.where(win, cnt, best)
+        arg = np.where(win, lab, arg)
+    out[h:n - h] = arg
+    return out
+
+
 def smooth_labels(Predictions, PtdLabels, win_size, smooth_type="prediction"):
-    """DAFx12...:94-98 -> (Predictions_smooth, PtdLabels_smooth)."""
+    """DAFx12...:94-103 -> (Predictions_smooth, PtdLabels_smooth)."""
+    if smooth_type == "label":
+        return Predictions, mode_filtering(PtdLabels, win_size)
     if smooth_type != "prediction":
-        raise NotImplementedError("only smooth_type='prediction' (median of the probability track) is built; the "
-                                  "'label' mode filter of :81-89 is plotting support")
+        raise ValueError("smooth_type must be 'prediction' or 'label'")
     sm = medfilt(Predictions, win_size)
     lab = (sm > 0.5).astype(int) if isinstance(sm, np.ndarray) else (sm > 0.5).to(torch.int64)
     return sm, lab

@@ -156,3 +156,22 @@ def test_h5_weight_files_round_trip(tmp_path):
     # any other extension keeps the .npz form
     p2 = persistence.save_weights_file(str(tmp_path / "weights"), w)
     assert p2.endswith(".npz") and np.array_equal(persistence.load_weights_file(str(tmp_path / "weights"))["3C/kernel"], w["3C/kernel"])
+
+
+def test_mode_filtering_matches_the_reference_loop():
+    """DAFx12_Speech_Music_Detection_B3_MTL_v2.py:81-89 restated literally vs the prefix-sum form."""
+    from sm_hpss_mtl_amd.inference import mode_filtering
+
+    def ref(X, win_size):
+        if win_size % 2 == 0:
+            win_size += 1
+        Xs = X.copy()
+        for i in range(int(win_size / 2), len(X) - int(win_size / 2)):
+            win = X[i - int(win_size / 2):i + int(win_size / 2)]
+            lab, cnt = np.unique(win, return_counts=True)
+            Xs[i] = lab[np.argmax(cnt)]
+        return Xs
+    rng = np.random.default_rng(0)
+    for n, w, k in [(200, 11, 2), (500, 50, 2), (64, 5, 3), (30, 501, 2), (7, 3, 2), (300, 2, 4)]:
+        X = rng.integers(0, k, n)
+        assert np.array_equal(mode_filtering(X, w), ref(X, w)), (n, w, k)
