@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .persistence import ModelSurfaceMixin
 from .cnn_training import CnnTrainingMixin
 from .model import head_spec
 
@@ -27,7 +28,7 @@ KINDS = {"Doukhan": 0, "Papakostas": 1, "Jang": 2}
 LEARNING_RATE = {"Doukhan": 0.0001, "Papakostas": 0.001, "Jang": 0.001}
 
 
-class CnnMTL(CnnTrainingMixin):
+class CnnMTL(CnnTrainingMixin, ModelSurfaceMixin):
     """`model` object of get_{Doukhan,Papakostas,Jang}_MTL_model."""
 
     def __init__(self, kind, input_shape, n_classes=3, seed=None, n_mels=120, n_fft=512, fs=16000, fc_width=0,

@@ -41,4 +41,4 @@ def get_Jang_MTL_model(PARAMS, fs=16000, Tw=25, n_mels=120, t_dim=5, n_classes=3
 
 
 # tensorflow.keras.models.model_from_json at the reference's call site (Proposed_Work_Results.py:381-383)
-from ..persistence import model_from_json  # noqa: E402,F401
+from ..persistence import Model, model_from_json  # noqa: E402,F401

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .persistence import ModelSurfaceMixin
 from .training import TrainingMixin
 
 
@@ -50,7 +51,7 @@ def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_
     return spec
 
 
-class B3MTL(TrainingMixin):
+class B3MTL(TrainingMixin, ModelSurfaceMixin):
     """`model` object of get_Lemaire_MTL_model.  Inference runs entirely in libsmh (HIP)."""
 
     def __init__(self, n_feat=240, patch_size=68, n_classes=3, TR_STEPS=1, loss_weights=None, seed=None,

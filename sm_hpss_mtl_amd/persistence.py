@@ -62,3 +62,50 @@ def model_from_json(text, seed=None):
         return CnnMTL(name[:-4], tuple(cfg["input_shape"]), n_classes=cfg["n_classes"], seed=seed, n_mels=cfg.get("n_mels", 120),
                       n_fft=cfg.get("n_fft", 512), fs=cfg.get("fs", 16000), fc_width=cfg.get("fc_width", 0))
     raise ValueError("model_from_json: unknown class_name %r" % (name,))
+
+
+class _LayerRef:
+    """`model.get_layer(name)`: only the named outputs of the MTL graphs can be addressed ('S', 'M', 'N', 'R', '3C')."""
+
+    def __init__(self, model, name):
+        if name not in model.output_names:
+            raise ValueError("get_layer(%r): the layers that can be addressed are the outputs %s" % (name, model.output_names))
+        self.model, self.name = model, name
+        self.output = self  # what Model(inputs, outputs) receives
+
+
+class HeadModel:
+    """`Model(trained_model.input, trained_model.get_layer('M').output)` of the DAFx driver
+    (DAFx12_Speech_Music_Detection_B3_MTL_v2.py:518-523): the same network, one output.  Inference only (the
+    driver's optional Nadam fine-tuning of the sub-model is not built)."""
+
+    def __init__(self, model, name):
+        self.model, self.name = model, name
+        self._index = model.output_names.index(name)
+        self.output_names = [name]
+        self.input = model.input
+
+    def predict(self, x, batch_size=None, verbose=0, **kw):
+        return self.model.predict(x, **kw)[self._index]
+
+    def summary(self, print_fn=print):
+        print_fn("Model: output %r of" % self.name)
+        self.model.summary(print_fn=print_fn)
+
+
+def Model(inputs, outputs):
+    """tensorflow.keras.models.Model at the one call shape the reference uses on a trained MTL model."""
+    if isinstance(outputs, _LayerRef) and inputs is outputs.model.input:
+        return HeadModel(outputs.model, outputs.name)
+    raise TypeError("Model(inputs, outputs): expected (model.input, model.get_layer(name).output) of one of our models")
+
+
+class ModelSurfaceMixin:
+    """`input` and `get_layer` for B3MTL / CnnMTL."""
+
+    @property
+    def input(self):
+        return self  # identity token: only ever passed back to Model()
+
+    def get_layer(self, name):
+        return _LayerRef(self, name)

@@ -50,3 +50,19 @@ def test_patch_probabilities_vs_oracle(head):
     ref = oinf.patch_probabilities(fv, w, 68, 1, output=head, batch_frames=120)
     assert got.shape == ref.shape and got.shape[0] == 2 * (120 - 68) + len(ofe.patch_starts(116, 68, 1))
     assert np.max(np.abs(got - ref)) <= 1e-4
+
+
+def test_head_sub_model_as_the_dafx_driver_builds_it():
+    """DAFx12...:518-523: Model(trained_model.input, trained_model.get_layer('M').output).predict(x)."""
+    from sm_hpss_mtl_amd.lib.proposed_architectures import Model, get_Lemaire_MTL_model
+    trained_model, _ = get_Lemaire_MTL_model(100, 240, 3, 99, seed=4)
+    x = np.random.default_rng(1).standard_normal((5, 99, 240)).astype(np.float32)
+    full = trained_model.predict(x)
+    for name in ("M", "S"):
+        sub = Model(trained_model.input, trained_model.get_layer(name).output)
+        got = sub.predict(x=x)
+        assert got.shape == (5, 1) and np.array_equal(got, full[trained_model.output_names.index(name)])
+    with pytest.raises(ValueError):
+        trained_model.get_layer("dense_7")
+    with pytest.raises(TypeError):
+        Model(None, trained_model.get_layer("M").output)
