@@ -5,7 +5,7 @@ reference's hot path -- the librosa/scipy/sklearn/Cython front end of ``lib/prep
 the keras / keras-tcn B3_MTL network of ``lib/proposed_architectures.py``.  It exists so that the
 HIP product path can be checked against something that is *not* itself.
 
-Rules (enforced by ``tests/test_layout_rules.py``):
+Rules (enforced by ``tests/test_host_logic.py::test_product_never_imports_oracle``):
 
 * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
   anything from here; the product package ``sm_hpss_mtl_amd`` never does and has no CPU fallback;

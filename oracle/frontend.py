@@ -223,6 +223,16 @@ def featuregram(y: np.ndarray, featName: str = "LogMelHarmPercSpec", n_fft: int 
     frameSize = int(Tw * fs / 1000)
     frameShift = int(Ts * fs / 1000)
     S = stft_mag(y, n_fft=n_fft, win_length=frameSize, hop=frameShift)
+    return featuregram_from_S(S, featName, n_mels=n_mels, l_harm=l_harm, l_perc=l_perc, return_parts=return_parts)
+
+
+def featuregram_from_S(S: np.ndarray, featName: str = "LogMelHarmPercSpec", n_mels: int = 120, l_harm: int = 21,
+                       l_perc: int = 11, return_parts: bool = False):
+    """Everything of the '*HarmPerc*' branches behind `np.abs(librosa.core.stft(...))`
+    (lib/preprocessing.py:408-412, 418-424, 430-434, 440-444), starting from a GIVEN magnitude spectrogram.
+    Parity tests feed the device's own S here: the medians are then selections of identical values, so the
+    dB outputs can be held to abs 1e-3 on every bin (no selection flips caused by the STFT's last ulp)."""
+    S = np.asarray(S, dtype=np.float32)
     H, P, harm, perc = hpss(S, l_harm, l_perc)
     if featName.startswith("MelHarm"):  # :404-412
         fv_H, fv_P = mel_project(H, n_mels), mel_project(P, n_mels)

@@ -51,6 +51,25 @@ def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_
     return spec
 
 
+def initial_weights(n_feat=240, patch_size=68, n_classes=3, seed=None, nb_filters=32, kernel_size=3, nb_stacks=3,
+                    n_dilations=8):
+    """(dropout_rate, OrderedDict name -> float32 array) of a freshly built model: Keras defaults (glorot_uniform
+    kernels, zero biases, BatchNormalization gamma = moving_variance = 1) and the build-time draw of the spatial
+    dropout rate (proposed_architectures.py:136).  Host-only (numpy): `B3MTL.__init__` and the generator of
+    tests/golden/bench_golden.npz both call it, so `B3MTL(seed=s)` is reproducible without a GPU."""
+    rng = np.random.default_rng(seed)
+    dropout_rate = float(rng.uniform(0.05, 0.5))
+    weights = OrderedDict()
+    for name, shape, fan_in, fan_out in weight_spec(n_feat, patch_size, n_classes, nb_filters, kernel_size, nb_stacks,
+                                                    n_dilations):
+        if fan_out is not None:
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            weights[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        else:
+            weights[name] = np.full(shape, float(fan_in), np.float32)
+    return dropout_rate, weights
+
+
 class B3MTL(TrainingMixin, ModelSurfaceMixin):
     """`model` object of get_Lemaire_MTL_model.  Inference runs entirely in libsmh (HIP)."""
 
@@ -60,9 +79,9 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         self.n_feat, self.patch_size, self.n_classes = int(n_feat), int(patch_size), int(n_classes)
         self.nb_filters, self.kernel_size, self.nb_stacks, self.n_dilations = nb_filters, kernel_size, nb_stacks, n_dilations
         self.TR_STEPS, self.loss_weights = TR_STEPS, loss_weights
-        rng = np.random.default_rng(seed)
         # proposed_architectures.py:136 draws the (training-only) spatial dropout rate at build time
-        self.dropout_rate = float(rng.uniform(0.05, 0.5))
+        self.dropout_rate, self.weights = initial_weights(self.n_feat, self.patch_size, self.n_classes, seed, nb_filters,
+                                                          kernel_size, nb_stacks, n_dilations)
         self.initial_learning_rate = 0.002
         cfg = _lib.ModelCfg(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
         h = C.c_void_p()
@@ -70,13 +89,6 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         self._h = h
         self.out_dim = self.lib.smh_model_out_dim(self._h)
         self._spec = weight_spec(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
-        self.weights = OrderedDict()
-        for name, shape, fan_in, fan_out in self._spec:  # Keras defaults: glorot_uniform / zeros / BN ones
-            if fan_out is not None:
-                lim = np.sqrt(6.0 / (fan_in + fan_out))
-                self.weights[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
-            else:
-                self.weights[name] = np.full(shape, float(fan_in), np.float32)
         assert self.count_params() == self.lib.smh_model_num_params(self._h)
         self._dirty = True          # host copy newer than the device master
         self._device_newer = False  # device master newer than the host copy (after optimiser steps)

@@ -19,7 +19,7 @@ def _json_line(cmd):
 
 
 def test_bench_contract():
-    d = _json_line(["bench.py", "--steps", "4", "--warmup", "1", "--batch", "128"])
+    d = _json_line(["bench.py", "--steps", "4", "--warmup", "1", "--batch", "128", "--cpu-budget", "2"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -31,10 +31,25 @@ def test_bench_contract():
     assert rf["bound"] in ("hbm", "mfma") and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "clips/s" and cb["sample"]
+    assert "scipy.ndimage.median_filter" in cb["routine"] and cb["cpu_model"] and cb["host_cores_usable"] >= 1
+    if cb["host_cores_usable"] > 1:  # the all-cores leg: a process pool over clips
+        assert cb["all_cores"]["cores"] > 1 and cb["all_cores"]["value"] > cb["value"]
     assert set(d["kernels"]) >= {"stft", "median", "features", "model"}
+    # the timed configuration was checked against the oracle's committed logits inside bench.py
+    pr = d["parity"]
+    assert pr["checked"] is True and pr["argmax_3C_identical"] is True and pr["max_abs_logit_diff_vs_oracle_golden"] <= pr["tol"]
+    assert d["config"]["harm_layout"] == 2 and d["ranks_reporting"] == 1
 
 
 def test_bench_train_contract():
     d = _json_line(["tools/bench_train.py", "--steps", "3", "--warmup", "1", "--batch", "48"])
     assert d["unit"] == "clips/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["gradient_allreduce_bytes"] == 0
     assert set(d["last_losses"]) == {"loss", "S_loss", "M_loss", "R_loss", "3C_loss", "3C_accuracy"}
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and '{"metric"' not in r.stdout

@@ -1,0 +1,57 @@
+"""`bench.py --gpus N` starts its own ranks: the launcher path rehearsed on the CPU with gloo (world size 2), and the
+refusal to time fewer GPUs than asked for.  No hot-path compute happens here (that needs a GPU: tests/test_bench_gpu.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env_extra=None, timeout=240):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable] + cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("script", ["bench.py", "tools/bench_train.py"])
+def test_self_launch_two_ranks_gloo(script):
+    r = _run([script, "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], {"SMH_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout  # exactly one line, from rank 0, relayed by the parent
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reporting"] == 2 and d["dry_run"] is True and d["value"] is None
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["backend"] == "gloo"
+
+
+def test_more_gpus_than_visible_is_an_error():
+    import torch
+    have = torch.cuda.device_count()
+    r = _run(["bench.py", "--gpus", str(have + 2), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_world_size_must_match_gpus_flag():
+    """Under a launcher: `--gpus 4` with WORLD_SIZE=2 must not silently report either number."""
+    r = _run(["bench.py", "--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                       "SMH_DIST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_parent_does_not_load_the_hip_library():
+    """The parent of the ranks must never touch the GPU: spawn_ranks_if_needed runs before libsmh is loaded."""
+    code = ("import sys; sys.argv=['bench.py','--gpus','2','--dry-run','--steps','1','--warmup','0'];"
+            "import os; os.environ['SMH_DIST_BACKEND']='gloo';"
+            "import runpy\n"
+            "try:\n  runpy.run_path('bench.py', run_name='__main__')\n"
+            "except SystemExit as e:\n  assert e.code == 0, e.code\n"
+            "from sm_hpss_mtl_amd import _lib; assert _lib._lib is None, 'parent loaded libsmh.so'\n"
+            "import torch; assert not torch.cuda.is_initialized()")
+    r = _run(["-c", code])
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -32,8 +32,8 @@ def _flat_to_dict(model, flat):
 
 
 @pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68),
-                                      (3, 3, 99),    # DAFx12...:760 -- longer than the MFMA backward covers: scalar kernel
-                                      (3, 2, 249)])  # Proposed_Work_Results.py:724 -- scalar kernel without the transposed LDS copies
+                                      (3, 3, 99),    # DAFx12...:760 -- MFMA backward, T <= 128 instantiation
+                                      (3, 2, 249)])  # Proposed_Work_Results.py:724 -- MFMA backward, T <= 256 instantiation (kernels read from global memory)
 def test_gradients_and_losses_vs_oracle(ncls, N, W):
     from sm_hpss_mtl_amd.model import B3MTL
     w, x, y, drop_tcn, drop_heads = _problem(ncls, N, W=W)

@@ -1,8 +1,9 @@
 """End-to-end TRAINING throughput (BASELINE config 4's shape): per step and per GPU, `--batch` synthetic 1 s clips
 (music | speech | mixtures, labels cycling, SMR -5..20 dB) -> HIP front end (STFT -> HPSS 21x11 -> log-mel ->
 standardise -> W=68 patches, with the reference's Gaussian noise augmentation) -> B3_MTL training step (training forward,
-losses, backward, ONE all-reduce of the flat gradient over RCCL when WORLD_SIZE > 1, SGD with momentum and clipnorm).
-Launch like bench.py:  python tools/bench_train.py            (1 GPU)
+losses, backward, ONE all-reduce of the flat gradient + BatchNorm batch statistics over RCCL when WORLD_SIZE > 1, SGD with
+momentum and clipnorm).
+Launch like bench.py:  python tools/bench_train.py [--gpus N]     (starts its own N ranks; the parent never touches the GPU)
                        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
 Prints one JSON line on rank 0.  Not the headline metric (bench.py is); documents the training path end to end."""
 import argparse
@@ -11,10 +12,9 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def main():
@@ -26,14 +26,24 @@ def main():
     ap.add_argument("--classes", type=int, default=3, choices=[3, 5])
     ap.add_argument("--patch", type=int, default=68, help="patch width W (68; the reference's drivers also use 99 and 249)")
     ap.add_argument("--shift", type=int, default=0, help="patch shift (default: W, 24 for W = 249 as in Proposed_Work_Results.py:724-725)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal (SMH_DIST_BACKEND=gloo on a CPU box): no compute")
     args = ap.parse_args()
-    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from sm_hpss_mtl_amd.launch import init_ranks, spawn_ranks_if_needed, timed_region
+    rc = spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:  # parent of the ranks: never touched the GPU
+        sys.exit(rc)
+    ranks = init_ranks(args.gpus)
+    rank, world = ranks.rank, ranks.world
+    if args.dry_run:
+        elapsed, ran = timed_region(ranks, lambda k, timed: time.sleep(0.001), args.steps, args.warmup, lambda: None)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher dry run (no training step executed)", "value": None, "unit": "clips/s",
+                              "n_gpus": world, "ranks_reporting": ran, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(1e3 * elapsed / args.steps, 4), "dry_run": True, "backend": ranks.backend}))
+        ranks.close()
+        return
+    import numpy as np
+    import torch
     from sm_hpss_mtl_amd.batching import make_labels_3class, make_labels_5class
     from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
     from sm_hpss_mtl_amd.model import B3MTL
@@ -71,28 +81,20 @@ def main():
             ev[2].record()
         return r
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    last = [None]
+
+    def one(k, timed):
+        last[0] = step()
+
+    dt, ran = timed_region(ranks, one, args.steps, args.warmup, torch.cuda.synchronize, audio.device)
+    assert ran == world
+    last = last[0]
     step(timed=True)
     torch.cuda.synchronize()
     if rank == 0:
         print(json.dumps({
             "metric": "clips/sec HPSS + B3_MTL training step (1s@16kHz)", "value": round(world * B * args.steps / dt, 1),
-            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "clips/s", "n_gpus": world, "ranks_reporting": ran, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "dtype": "f32",
             "data": "synthetic", "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=%d patches (%d per clip) -> B3_MTL(%d-class) "
                                             "train step, SGD(momentum 0.9, clipnorm 1)" % (B, W, nP, args.classes),
@@ -100,8 +102,7 @@ def main():
             "stages_ms": {"front_end_and_augmentation": round(ev[0].elapsed_time(ev[1]), 4),
                           "train_step_incl_allreduce_and_host_sync": round(ev[1].elapsed_time(ev[2]), 4)},
             "last_losses": dict(zip(model.metrics_names, [round(float(v), 5) for v in last]))}))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
