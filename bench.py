@@ -44,10 +44,9 @@ BYTES = {
     "features": 3 * K_BINS * T_FRAMES * 4 + 2 * FEAT * T_FRAMES * 4 + W_PATCH * FEAT * 4,  # S,h,p in; fv out, re-read; patches out
 }
 FLOPS_MODEL = 2.0 * (W_PATCH * FEAT * 32 + 24 * W_PATCH * (3 * 32 * 32 + 32 * 32) + W_PATCH * 32 * 51)  # 14.64 MFLOP
-# full-chain tolerance of the golden check: the oracle starts from numpy's f64 FFT, the device from its own f32 STFT
-# (1e-5 relative), a few medians then select a neighbouring value, dB moves by <= 2e-2 in those bins.  Measured on
-# MI355X: see DESIGN.md section 6.  (With identical patches the network alone agrees to 1e-4: tests/.)
-GOLDEN_LOGIT_TOL = 2e-3
+# full-chain tolerance of the golden check (oracle from audio: numpy f64 FFT; device: its own f32 STFT): the same
+# abs 1e-4 SURVEY 8(d') asks of the network alone.  Measured on MI355X: 2.9e-6.
+GOLDEN_LOGIT_TOL = 1e-4
 
 
 def cpu_baseline(l_harm, l_perc, budget_s):

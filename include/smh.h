@@ -286,6 +286,12 @@ typedef struct smh_cnn_trainer smh_cnn_trainer;
 int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer **out);
 void smh_cnn_trainer_destroy(smh_cnn_trainer *t);
 float *smh_cnn_trainer_grad_ptr(smh_cnn_trainer *t);
+/* floats of the data-parallel bucket that starts at smh_cnn_trainer_grad_ptr: [gradient | BatchNorm batch statistics]
+ * (all-reduce all of it: the moving statistics then follow the mean over the ranks) */
+size_t smh_cnn_trainer_bucket_floats(const smh_cnn_trainer *t);
+/* copy the optimiser state (Adam moments / momentum, step counter) of `src` into `dst` (same model): a trainer that has
+ * to grow for a larger batch keeps its state (create the larger one, copy, destroy the old one) */
+int smh_cnn_trainer_copy_state(smh_cnn_trainer *dst, const smh_cnn_trainer *src, void *stream);
 int smh_cnn_trainer_num_dropouts(const smh_cnn_trainer *t);
 int smh_cnn_trainer_dropout_info(const smh_cnn_trainer *t, int i, size_t *dim, float *rate);
 int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop,
@@ -308,13 +314,33 @@ float *smh_trainer_grad_ptr(smh_trainer *t);
  *   d_drop_tcn  (N, n_blocks, 32) SpatialDropout1D masks (0 or 1/(1-rate)) or NULL (no dropout)
  *   d_drop_heads (N, n_heads, 16) Dropout(0.4) masks (0 or 1/0.6) or NULL
  *   h_loss_weights: n_heads + 1 host floats in output order (NULL = all 1)
- *   d_losses: n_heads + 4 floats out = [per-head losses..., 3C loss, weighted sum (without the l2 term), 3C accuracy,
- *             l2(0.01) penalty of the Dense(16) kernels = the term Keras adds to the reported total] */
+ *   d_losses: 3 * n_heads + 4 floats out = [per-head losses..., 3C loss, weighted sum (without the l2 term), 3C accuracy,
+ *             l2(0.01) penalty of the Dense(16) kernels = the term Keras adds to the reported total,
+ *             that penalty per head (n_heads), binary accuracy (threshold 0.5) of every sigmoid head (n_heads)] */
 int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
                        const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream);
 /* g = grad * grad_scale (+ l2 term); per-tensor clip to `clipnorm` (<= 0: off); v = momentum*v - lr*g; w += v;
  * BN moving statistics <- 0.99*old + 0.01*batch; operand buffers re-packed on the device.              */
 int smh_trainer_apply_sgd_f32(smh_trainer *t, float lr, float momentum, float clipnorm, float grad_scale, void *stream);
+/* floats of the data-parallel bucket that starts at smh_trainer_grad_ptr: [gradient (num_params) | BatchNorm batch
+ * statistics of the heads]; all-reduce all of it so the moving statistics follow the mean over the ranks. */
+size_t smh_trainer_bucket_floats(const smh_trainer *t);
+/* copy momentum / Adam moments / step counters from `src` to `dst` (same model): growing a trainer keeps its state */
+int smh_trainer_copy_state(smh_trainer *dst, const smh_trainer *src, void *stream);
+/* zero the optimiser state (what compiling a Keras model with a new optimiser does) */
+int smh_trainer_reset_state(smh_trainer *t, void *stream);
+/* General optimiser step.  optimizer 0 = SGD (beta1 = momentum; what smh_trainer_apply_sgd_f32 calls), 1 = Adam,
+ * 2 = Nadam as tf.keras 2.x implements it (momentum schedule u_t = beta1 (1 - 0.5 * 0.96^(0.004 t)); the optimiser of the
+ * single-head fine-tuning in DAFx12_Speech_Music_Detection_B3_MTL_v2.py:524-526).  active_mask selects the tensors that
+ * belong to the (sub-)model being trained: bit 0 the TCN trunk, bit 1 the '3C' Dense, bit 2 + h head h (dense, BatchNorm
+ * incl. moving statistics, output layer); tensors outside the mask are left untouched (Model(input,
+ * get_layer('M').output) owns the trunk and head M only).  clipnorm <= 0: off.                                       */
+#define SMH_TRAIN_TRUNK 1u
+#define SMH_TRAIN_3C 2u
+#define SMH_TRAIN_HEAD(h) (4u << (h))
+#define SMH_TRAIN_ALL 0xFFFFFFFFu
+int smh_trainer_apply_f32(smh_trainer *t, int optimizer, float lr, float beta1, float beta2, float eps, float clipnorm,
+                          float grad_scale, unsigned active_mask, void *stream);
 
 #ifdef __cplusplus
 }

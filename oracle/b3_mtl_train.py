@@ -206,3 +206,42 @@ def sgd_step(w, grads, velocity, bn_batch, lr, momentum=0.9, clipnorm=1.0):
 def exponential_decay(step, initial=0.002, decay_steps=1, rate=0.1):
     """tf.keras ExponentialDecay (staircase False): initial * rate ** (step / decay_steps)."""
     return initial * rate ** (step / float(decay_steps))
+
+
+def adam_step(w, grads, state, lr, names=None, beta_1=0.9, beta_2=0.999, eps=1e-7):
+    """tf.keras.optimizers.Adam (2.x): m, v moments; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps).
+    state: dict(t=int, m={}, v={}); names: tensors to update (None = all trainable)."""
+    t = state.get("t", 0) + 1
+    m, v = dict(state.get("m", {})), dict(state.get("v", {}))
+    alpha = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    new_w = {k: np.asarray(val, np.float64) for k, val in w.items()}
+    for k in (names if names is not None else [k for k in w if not k.endswith(TRAINABLE_SKIP)]):
+        g = np.asarray(grads[k], np.float64)
+        m[k] = beta_1 * np.asarray(m.get(k, 0.0)) + (1 - beta_1) * g
+        v[k] = beta_2 * np.asarray(v.get(k, 0.0)) + (1 - beta_2) * g * g
+        new_w[k] = new_w[k] - alpha * m[k] / (np.sqrt(v[k]) + eps)
+    return new_w, dict(t=t, m=m, v=v)
+
+
+def nadam_step(w, grads, state, lr, names=None, beta_1=0.9, beta_2=0.999, eps=1e-7, schedule_decay=0.004):
+    """tf.keras.optimizers.Nadam (2.x) -- the optimiser of the sub-model fine-tuning in
+    DAFx12_Speech_Music_Detection_B3_MTL_v2.py:524-526 ("parity unpinned": restated from the published Keras source):
+      u_t = b1 (1 - 0.5 * 0.96^(decay t)),  u_{t+1} likewise;  M_t = prod_{i<=t} u_i (a running product kept by the optimiser)
+      g' = g / (1 - M_t);  m_t = b1 m + (1-b1) g;  m' = m_t / (1 - M_t u_{t+1});  v_t = b2 v + (1-b2) g^2;  v' = v_t / (1 - b2^t)
+      w -= lr * ((1 - u_t) g' + u_{t+1} m') / (sqrt(v') + eps)."""
+    t = state.get("t", 0) + 1
+    m, v = dict(state.get("m", {})), dict(state.get("v", {}))
+    u_t = beta_1 * (1.0 - 0.5 * 0.96 ** (schedule_decay * t))
+    u_t1 = beta_1 * (1.0 - 0.5 * 0.96 ** (schedule_decay * (t + 1)))
+    ms_new = state.get("m_schedule", 1.0) * u_t
+    ms_next = ms_new * u_t1
+    new_w = {k: np.asarray(val, np.float64) for k, val in w.items()}
+    for k in (names if names is not None else [k for k in w if not k.endswith(TRAINABLE_SKIP)]):
+        g = np.asarray(grads[k], np.float64)
+        gp = g / (1.0 - ms_new)
+        m[k] = beta_1 * np.asarray(m.get(k, 0.0)) + (1 - beta_1) * g
+        mp = m[k] / (1.0 - ms_next)
+        v[k] = beta_2 * np.asarray(v.get(k, 0.0)) + (1 - beta_2) * g * g
+        vp = v[k] / (1.0 - beta_2 ** t)
+        new_w[k] = new_w[k] - lr * ((1.0 - u_t) * gp + u_t1 * mp) / (np.sqrt(vp) + eps)
+    return new_w, dict(t=t, m=m, v=v, m_schedule=ms_new)

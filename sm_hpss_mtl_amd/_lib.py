@@ -70,6 +70,8 @@ SIGNATURES = {
     "smh_cnn_trainer_create": (_i, [_vp, _i, C.POINTER(C.c_void_p)]),
     "smh_cnn_trainer_destroy": (None, [_vp]),
     "smh_cnn_trainer_grad_ptr": (_vp, [_vp]),
+    "smh_cnn_trainer_bucket_floats": (_sz, [_vp]),
+    "smh_cnn_trainer_copy_state": (_i, [_vp, _vp, _vp]),
     "smh_cnn_trainer_num_dropouts": (_i, [_vp]),
     "smh_cnn_trainer_dropout_info": (_i, [_vp, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
     "smh_cnn_train_step_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -104,6 +106,10 @@ SIGNATURES = {
     "smh_trainer_grad_ptr": (_vp, [_vp]),
     "smh_train_step_f32": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp, _fp, _vp]),
     "smh_trainer_apply_sgd_f32": (_i, [_vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    "smh_trainer_bucket_floats": (_sz, [_vp]),
+    "smh_trainer_copy_state": (_i, [_vp, _vp, _vp]),
+    "smh_trainer_reset_state": (_i, [_vp, _vp]),
+    "smh_trainer_apply_f32": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint, _vp]),
 }
 
 _lib = None

@@ -3,8 +3,7 @@
     python -m sm_hpss_mtl_amd.build [--force]
 
 hipcc cross-compiles without a GPU; the built library travels to the GPU box with the snapshot
-(*.so is git-ignored, not gpurun-ignored; only the reference's
-compiled checker oracle/_ref/ stays behind).  No torch, no pybind: the boundary is a plain C ABI.
+(*.so is git-ignored, not gpurun-ignored).  No torch, no pybind: the boundary is a plain C ABI.
 """
 from __future__ import annotations
 

@@ -13,12 +13,19 @@ import ctypes as C
 import numpy as np
 import torch
 
+import os
+
 from . import _lib
+from . import optimizers as _opt
 from .training import HEAD_DROPOUT, TrainingMixin, _cur_stream
 
 
 class CnnTrainingMixin(TrainingMixin):
-    """Mixed into sm_hpss_mtl_amd.cnn_models.CnnMTL; fit / evaluate / pack_targets come from TrainingMixin."""
+    """Mixed into sm_hpss_mtl_amd.cnn_models.CnnMTL; compile / fit / evaluate / pack_targets come from TrainingMixin."""
+
+    _TRAINER_API = ("smh_cnn_trainer_create", "smh_cnn_trainer_destroy", "smh_cnn_trainer_copy_state", "smh_cnn_trainer_grad_ptr",
+                    "smh_cnn_trainer_bucket_floats")
+    _MIN_TRAINER_CAP = 48
 
     def _init_training_state(self):
         self._trainer = None
@@ -26,33 +33,37 @@ class CnnTrainingMixin(TrainingMixin):
         self._grad_view = None
         self._drop_spec = []
         self.iterations = 0
-        self.optimizer = "sgd" if self.kind == "Papakostas" else "adam"
-        self.beta_1, self.beta_2, self.epsilon, self.momentum = 0.9, 0.999, 1e-7, 0.0
-        self.decay_steps, self.decay_rate = 700, 0.1
+        self.stop_training = False
+        if self.kind == "Papakostas":  # lib/proposed_architectures.py:572-574
+            self.optimizer = _opt.SGD(learning_rate=_opt.ExponentialDecay(self.initial_learning_rate, 700, 0.1))
+        else:                           # :499-500 (Doukhan, 1e-4), :750-751 (Jang, 1e-3)
+            self.optimizer = _opt.Adam(learning_rate=self.initial_learning_rate)
         self._rng = torch.Generator(device="cuda")
-        self._rng.manual_seed(1234)
+        self._rng.manual_seed(1234 + int(os.environ.get("RANK", "0")))
 
-    def learning_rate(self, step=None):
-        step = self.iterations if step is None else step
-        if self.kind == "Papakostas":  # ExponentialDecay(0.001, decay_steps=700, decay_rate=0.1), not staircase
-            return self.initial_learning_rate * self.decay_rate ** (step / float(self.decay_steps))
-        return self.initial_learning_rate
+    def _set_optimizer(self, optimizer):
+        if optimizer.kind not in ("sgd", "adam"):
+            raise ValueError("the Conv2D MTL models train with SGD or Adam (as the reference compiles them), not %s" % optimizer.kind)
+        if optimizer.clipnorm:
+            raise ValueError("clipnorm is not part of the Conv2D MTL models' optimisers")
+        self.optimizer = optimizer
+        self.iterations = 0
+        self._reset_optimizer_state()
 
-    def _get_trainer(self, n):
-        if self._trainer is None or n > self._trainer_cap:
-            if self._trainer is not None:
-                self.lib.smh_cnn_trainer_destroy(self._trainer)
-                self._trainer = None
-            cap = max(n, 48)
-            h = C.c_void_p()
-            _lib.check(self.lib.smh_cnn_trainer_create(self._h, cap, C.byref(h)), "smh_cnn_trainer_create")
-            self._trainer, self._trainer_cap, self._grad_view = h, cap, None
-            self._drop_spec = []
-            dim, rate = C.c_size_t(), C.c_float()
-            for i in range(self.lib.smh_cnn_trainer_num_dropouts(h)):
-                _lib.check(self.lib.smh_cnn_trainer_dropout_info(h, i, C.byref(dim), C.byref(rate)), "smh_cnn_trainer_dropout_info")
-                self._drop_spec.append((int(dim.value), float(rate.value)))
-        return self._trainer
+    def _reset_optimizer_state(self):
+        if self._trainer is not None:  # a new trainer starts from zeroed moments and step 0
+            self.lib.smh_cnn_trainer_destroy(self._trainer)
+            self._trainer, self._trainer_cap, self._grad_view = None, 0, None
+
+    def _n_losses(self):
+        return len(self.output_names) - 1 + 4
+
+    def _on_new_trainer(self):
+        self._drop_spec = []
+        dim, rate = C.c_size_t(), C.c_float()
+        for i in range(self.lib.smh_cnn_trainer_num_dropouts(self._trainer)):
+            _lib.check(self.lib.smh_cnn_trainer_dropout_info(self._trainer, i, C.byref(dim), C.byref(rate)), "smh_cnn_trainer_dropout_info")
+            self._drop_spec.append((int(dim.value), float(rate.value)))
 
     def _l2_penalty(self):
         """0.01 * sum w^2 over the kernels that carry kernel_regularizer=l2(): the heads' Dense(16) kernels; for Jang every
@@ -68,23 +79,14 @@ class CnnTrainingMixin(TrainingMixin):
         self._get_trainer(n)
         return list(self._drop_spec)
 
-    def _grad_tensor(self):
-        if self._grad_view is None:
-            ptr = self.lib.smh_cnn_trainer_grad_ptr(self._trainer)
-            n = self.count_params()
-
-            class _Holder:
-                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
-            self._grad_view = torch.as_tensor(_Holder(), device="cuda")
-        return self._grad_view
-
     def gradients(self):
         """dict name -> gradient of the last train_on_batch(apply=False) (before grad_scale and the l2 term)."""
         flat = self._grad_tensor().cpu().numpy()
         return {name: flat[off:off + int(np.prod(shape))].reshape(shape).copy() for name, shape, off in self._spec}
 
-    def train_on_batch(self, x, y, drop="auto", drop_heads="auto", apply=True):
-        """One optimiser step.  Returns [loss, <per-output losses>, 3C_accuracy] like Keras.
+    def train_on_batch(self, x, y, drop="auto", drop_heads="auto", apply=True, sync=True):
+        """One optimiser step.  Returns [loss, <per-output losses>, 3C_accuracy] like Keras (sync=False: the raw device
+        tensor of the step's losses, see TrainingMixin.losses_to_list).
         drop: "auto" draws masks with the model's rates, None disables dropout, or a list of (N, dim_i) mask tensors
         (0 or 1/(1-rate_i)) in graph order; drop_heads likewise with one (N, n_heads, 16) tensor."""
         if isinstance(x, np.ndarray):
@@ -118,26 +120,18 @@ class CnnTrainingMixin(TrainingMixin):
             drop_heads = (torch.rand((n, n_heads, 16), device="cuda", generator=self._rng) < keep).float() / keep
         elif drop_heads is not None:
             drop_heads = torch.as_tensor(drop_heads, dtype=torch.float32).to("cuda")
-        losses = torch.empty(n_heads + 4, dtype=torch.float32, device="cuda")
+        losses = torch.empty(self._n_losses(), dtype=torch.float32, device="cuda")
         p = lambda t: None if t is None else C.c_void_p(t.contiguous().data_ptr())  # noqa: E731
         _lib.check(self.lib.smh_cnn_train_step_f32(tr, p(x), p(yt), n, p(drop), p(drop_heads), self._loss_weight_array(),
                                                    p(losses), _cur_stream()), "smh_cnn_train_step_f32")
         if apply:
             self.apply_gradients()
-        lv = losses.cpu().numpy()
-        reg = float(lv[n_heads + 3])
-        return [float(lv[n_heads + 1] + reg)] + [float(v) for v in lv[: n_heads + 1]] + [float(lv[n_heads + 2])]
+        return self.losses_to_list(losses) if sync else losses
 
-    def apply_gradients(self):
-        """All-reduce (if torch.distributed is initialised), then the optimiser update on the device."""
-        import torch.distributed as dist
-        scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self._grad_tensor(), op=dist.ReduceOp.SUM)  # one flat bucket over RCCL
-            scale = 1.0 / dist.get_world_size()
-        adam = self.optimizer == "adam"
-        _lib.check(self.lib.smh_cnn_trainer_apply_f32(self._trainer, 1 if adam else 0, self.learning_rate(),
-                                                      self.beta_1 if adam else self.momentum, self.beta_2, self.epsilon, scale,
+    def _apply_native(self, lr, scale, mask):
+        """The optimiser update on the device (the all-reduce of the bucket happens in TrainingMixin.apply_gradients)."""
+        o = self.optimizer
+        adam = o.kind == "adam"
+        _lib.check(self.lib.smh_cnn_trainer_apply_f32(self._trainer, 1 if adam else 0, lr, o.beta_1 if adam else o.momentum,
+                                                      getattr(o, "beta_2", 0.999), getattr(o, "epsilon", 1e-7), scale,
                                                       _cur_stream()), "smh_cnn_trainer_apply_f32")
-        self.iterations += 1
-        self._device_newer = True

@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) opt_kernel(const Seg *__restrict__ segs, 
     const Seg s = segs[blockIdx.x];
     if (s.kind >= 2) {
         for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x)
-            w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * bstat[s.aux + i];
+            w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * (bstat[s.aux + i] * o.grad_scale);
         return;
     }
     for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
@@ -618,7 +618,7 @@ struct smh_cnn_trainer {
     FoldEnt *d_foldents = nullptr;
     int nseg = 0, nfold = 0;
     unsigned head_bstat = 0;
-    size_t partial_floats = 0, g_floats = 0;
+    size_t partial_floats = 0, g_floats = 0, bstat_floats = 0;
     long step = 0;
 };
 
@@ -671,7 +671,7 @@ int col_reduce(smh_cnn_trainer *t, RedArgs r, int nv, float scale, int mode, flo
 extern "C" void smh_cnn_trainer_destroy(smh_cnn_trainer *t) {
     if (!t) return;
     for (float *p : {t->d_arena, t->d_g[0], t->d_g[1], t->d_partial, t->d_red, t->d_wt, t->d_chan, t->d_ones, t->d_zeros, t->d_tmp, t->d_pre,
-                     t->d_dpre, t->d_dxh, t->d_scratch, t->d_grad, t->d_s1, t->d_s2, t->d_bstat})
+                     t->d_dpre, t->d_dxh, t->d_scratch, t->d_grad, t->d_s1, t->d_s2})
         (void)hipFree(p);
     (void)hipFree(t->d_tables);
     (void)hipFree(t->d_l2part);
@@ -756,8 +756,10 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
     alloc(&t->d_ones, maxN), alloc(&t->d_zeros, maxN);
     alloc(&t->d_pre, NB * kPS), alloc(&t->d_dpre, NB * kPS), alloc(&t->d_dxh, NB * kPS);
     alloc(&t->d_scratch, NB * (size_t)m->out_dim);
-    alloc(&t->d_grad, m->n_params), alloc(&t->d_s1, m->n_params), alloc(&t->d_s2, m->n_params);
-    alloc(&t->d_bstat, bstat);
+    // ONE bucket [gradient (n_params) | BatchNorm batch statistics (bstat)]: what data-parallel training all-reduces
+    alloc(&t->d_grad, m->n_params + bstat), alloc(&t->d_s1, m->n_params), alloc(&t->d_s2, m->n_params);
+    t->bstat_floats = bstat;
+    if (e == hipSuccess) t->d_bstat = t->d_grad + m->n_params;
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_tables, std::max<size_t>(tables, 1) * sizeof(int2));
     if (e != hipSuccess)
         return smh::set_error(SMH_E_HIP, "smh_cnn_trainer_create: device allocation failed: %s", hipGetErrorString(e));
@@ -835,7 +837,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         if (e == hipSuccess && !folds.empty()) e = hipMemcpy(t->d_foldents, folds.data(), folds.size() * sizeof(FoldEnt), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(t->d_s1, 0, m->n_params * sizeof(float));
         if (e == hipSuccess) e = hipMemset(t->d_s2, 0, m->n_params * sizeof(float));
-        if (e == hipSuccess) e = hipMemset(t->d_grad, 0, m->n_params * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(t->d_grad, 0, (m->n_params + t->bstat_floats) * sizeof(float));
         if (e == hipSuccess) e = hipMemset(t->d_zeros, 0, maxN * sizeof(float));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(fill_kernel, dim3(nblk(maxN)), dim3(256), 0, 0, t->d_ones, maxN, 1.0f);
@@ -849,6 +851,17 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
 }
 
 extern "C" float *smh_cnn_trainer_grad_ptr(smh_cnn_trainer *t) { return t ? t->d_grad : nullptr; }
+extern "C" size_t smh_cnn_trainer_bucket_floats(const smh_cnn_trainer *t) { return t ? t->m->n_params + t->bstat_floats : 0; }
+extern "C" int smh_cnn_trainer_copy_state(smh_cnn_trainer *dst, const smh_cnn_trainer *src, void *stream) {
+    SMH_REQUIRE(dst && src && dst->m == src->m, "smh_cnn_trainer_copy_state: both trainers must belong to the same model");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = dst->m->n_params * sizeof(float);
+    SMH_CHECK_HIP(hipMemcpyAsync(dst->d_s1, src->d_s1, nb, hipMemcpyDeviceToDevice, st));
+    SMH_CHECK_HIP(hipMemcpyAsync(dst->d_s2, src->d_s2, nb, hipMemcpyDeviceToDevice, st));
+    SMH_CHECK_HIP(hipStreamSynchronize(st));  // the caller destroys `src` next
+    dst->step = src->step;
+    return SMH_OK;
+}
 extern "C" int smh_cnn_trainer_num_dropouts(const smh_cnn_trainer *t) { return t ? t->n_drop : SMH_E_INVALID; }
 
 extern "C" int smh_cnn_trainer_dropout_info(const smh_cnn_trainer *t, int i, size_t *dim, float *rate) {

@@ -10,6 +10,7 @@
 // Round-1 scope: CORRECT and device-resident.  The backward kernel recomputes each block from its saved
 // input with plain VALU loops in LDS and accumulates weight gradients with float atomics; moving it onto
 // the MFMA tiling of the forward kernel is the obvious next step.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -48,13 +49,14 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                    const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
                    float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses) {
     __shared__ float s_mean[64], s_inv[64], s_sum1[64], s_sum2[64], s_dgamma[64], s_dbeta[64], s_dbias[64];
-    __shared__ float s_dwo[kMaxHeads * kHidden * 3], s_dbo[kMaxHeads * 3], s_loss[kMaxHeads + 2], s_db3[8];
+    __shared__ float s_dwo[kMaxHeads * kHidden * 3], s_dbo[kMaxHeads * 3], s_loss[kMaxHeads + 2], s_db3[8], s_acc[kMaxHeads];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int N = a.N, ncls = a.n_classes, nh = a.n_heads, NJ = nh * kHidden;
     for (int i = tid; i < 64; i += nt) s_sum1[i] = s_sum2[i] = s_dgamma[i] = s_dbeta[i] = s_dbias[i] = 0.f;
     for (int i = tid; i < kMaxHeads * kHidden * 3; i += nt) s_dwo[i] = 0.f;
     if (tid < kMaxHeads * 3) s_dbo[tid] = 0.f;
     if (tid < kMaxHeads + 2) s_loss[tid] = 0.f;
+    if (tid < kMaxHeads) s_acc[tid] = 0.f;
     if (tid < 8) s_db3[tid] = 0.f;
     // A: batch statistics of every hidden unit (population variance, two passes): 16 lanes per unit
     {
@@ -109,11 +111,12 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                 ad[i] = fmaxf(bn[i], 0.f) * dm[i];
                 for (int c = 0; c < od; ++c) zo[c] = fmaf(ad[i], wo[i * od + c], zo[c]);
             }
-            float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f;
+            float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f, hit = 0.f;
             for (int c = 0; c < od; ++c) {
                 const float t = y[(size_t)nc * a.out_dim + col + c];
                 if (a.head_sigmoid[h]) {
                     const float o = 1.0f / (1.0f + expf(-zo[c]));
+                    hit += ((o > 0.5f) == (t > 0.5f)) ? 1.0f : 0.f;  // Keras binary_accuracy, threshold 0.5
                     const float oc = fminf(fmaxf(o, kKerasEps), 1.0f - kKerasEps);
                     lsum += -(t * logf(oc + kKerasEps) + (1.0f - t) * logf(1.0f - oc + kKerasEps));
                     const bool inside = (o > kKerasEps) && (o < 1.0f - kKerasEps);
@@ -128,6 +131,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                 wave_add(&s_dbo[h * 3 + c], dzo[c]);
             }
             wave_add(&s_loss[h], on ? lsum / (float)(N * od) : 0.f);
+            wave_add(&s_acc[h], on ? hit / (float)(N * od) : 0.f);
 #pragma unroll
             for (int i = 0; i < kHidden; ++i) {
                 const int j = h * kHidden + i;
@@ -206,6 +210,8 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         total += a.lw[nh] * s_loss[nh];
         losses[nh + 1] = total;           // without the l2 term (losses[nh + 3], l2_penalty_kernel)
         losses[nh + 2] = s_loss[nh + 1];  // 3C accuracy
+        if (a.ext_losses)                 // B3_MTL trainer: [2 nh + 4 + h] = binary accuracy of head h (training-mode outputs)
+            for (int h = 0; h < nh; ++h) losses[2 * nh + 4 + h] = s_acc[h];
     }
 }
 
@@ -746,33 +752,39 @@ __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const floa
 // step ran with: one workgroup, f64 accumulation.
 __global__ void __launch_bounds__(1024) l2_penalty_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ out) {
     __shared__ double sh[16];
-    double s = 0.0;
+    double total = 0.0;
     for (int h = 0; h < a.n_heads; ++h) {
+        double s = 0.0;
         const float *w = flatw + a.off.head[h];
         for (int i = threadIdx.x; i < a.D * kHidden; i += blockDim.x) s += (double)w[i] * (double)w[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) t += sh[w2];
+            out[1 + h] = (float)((double)kL2 * t);  // per head: the sub-model Model(input, get_layer(h).output) carries only its own
+            total += t;
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
-        out[0] = (float)((double)kL2 * t);
-    }
+    if (threadIdx.x == 0) out[0] = (float)((double)kL2 * total);
 }
 
 struct Segment {
     unsigned off, size;
-    int kind;  // 0 plain, 1 l2-regularised Dense(16) kernel, 2 BN moving_mean, 3 BN moving_variance
-    int aux;   // kinds 2/3: offset into the batch-statistics buffer
+    int kind;   // 0 plain, 1 l2-regularised Dense(16) kernel, 2 BN moving_mean, 3 BN moving_variance
+    int aux;    // kinds 2/3: offset into the batch-statistics part of the gradient bucket
+    int group;  // bit of `active_mask` this tensor belongs to: 0 trunk, 1 the '3C' Dense, 2 + h head h
 };
 
+// pass 1: g = grad * grad_scale (+ l2 term), written back; per-tensor sum of squares for clipnorm
 __global__ void seg_sumsq_kernel(const Segment *__restrict__ segs, const float *__restrict__ w, float *__restrict__ grad,
-                                 float grad_scale, float *__restrict__ sumsq) {
+                                 float grad_scale, unsigned active_mask, float *__restrict__ sumsq) {
     __shared__ float red[256];
     const Segment s = segs[blockIdx.x];
     float acc = 0.f;
-    if (s.kind <= 1)
+    if (s.kind <= 1 && ((active_mask >> s.group) & 1u))
         for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
             float g = grad[s.off + i] * grad_scale;
             if (s.kind == 1) g += 2.0f * kL2 * w[s.off + i];  // d/dw of l2 * sum(w^2)
@@ -788,21 +800,42 @@ __global__ void seg_sumsq_kernel(const Segment *__restrict__ segs, const float *
     if (threadIdx.x == 0) sumsq[blockIdx.x] = red[0];
 }
 
-__global__ void seg_sgd_kernel(const Segment *__restrict__ segs, float *__restrict__ w, const float *__restrict__ grad,
-                               float *__restrict__ vel, const float *__restrict__ sumsq, const float *__restrict__ bnstat,
-                               float lr, float momentum, float clipnorm) {
+// pass 2: the optimiser.  0 = SGD (Keras: v = momentum v - lr g; w += v), 1 = Adam, 2 = Nadam (tf.keras 2.x, see
+// smh_trainer_apply_f32); BatchNorm moving statistics <- 0.99 old + 0.01 batch (batch statistics averaged over the
+// data-parallel ranks by the same all-reduce as the gradient: they live behind it in one bucket).
+struct OptArgs {
+    int optimizer;
+    float lr, b1, b2, eps, clipnorm, grad_scale;
+    float alpha;                    // Adam: lr * sqrt(1 - b2^t) / (1 - b1^t)
+    float n_g, n_m, n_v;            // Nadam: m_bar = n_g * g + n_m * m_t;  v' = v_t * n_v
+    unsigned active_mask;
+};
+__global__ void seg_opt_kernel(const Segment *__restrict__ segs, OptArgs o, float *__restrict__ w, const float *__restrict__ grad,
+                               float *__restrict__ s1, float *__restrict__ s2, const float *__restrict__ sumsq,
+                               const float *__restrict__ bnstat) {
     const Segment s = segs[blockIdx.x];
+    if (!((o.active_mask >> s.group) & 1u)) return;
     if (s.kind >= 2) {
         for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x)
-            w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * bnstat[s.aux + i];
+            w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * (bnstat[s.aux + i] * o.grad_scale);
         return;
     }
     const float nrm = sqrtf(sumsq[blockIdx.x]);
-    const float scale = (clipnorm > 0.f && nrm > clipnorm) ? clipnorm / nrm : 1.0f;
+    const float scale = (o.clipnorm > 0.f && nrm > o.clipnorm) ? o.clipnorm / nrm : 1.0f;
     for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
-        const float v = momentum * vel[s.off + i] - lr * grad[s.off + i] * scale;
-        vel[s.off + i] = v;
-        w[s.off + i] += v;
+        const size_t k = (size_t)s.off + i;
+        const float g = grad[k] * scale;
+        if (o.optimizer == 0) {
+            const float v = o.b1 * s1[k] - o.lr * g;
+            s1[k] = v;
+            w[k] += v;
+        } else {
+            const float m = o.b1 * s1[k] + (1.0f - o.b1) * g;
+            const float v = o.b2 * s2[k] + (1.0f - o.b2) * g * g;
+            s1[k] = m, s2[k] = v;
+            if (o.optimizer == 1) w[k] -= o.alpha * m / (sqrtf(v) + o.eps);
+            else w[k] -= o.lr * (o.n_g * g + o.n_m * m) / (sqrtf(v * o.n_v) + o.eps);
+        }
     }
 }
 
@@ -817,9 +850,14 @@ int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const floa
 struct smh_trainer {
     smh_model *m;
     int max_batch, nseg;
-    float *d_acts = nullptr, *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr, *d_grad = nullptr, *d_vel = nullptr;
-    float *d_bnstat = nullptr, *d_sumsq = nullptr, *d_scratch_out = nullptr, *d_wtr = nullptr;
+    float *d_acts = nullptr, *d_pre = nullptr, *d_dpre = nullptr, *d_dxh = nullptr;
+    // ONE bucket [gradient (n_params) | BatchNorm batch statistics (kMaxHeads * 32)]: what data-parallel training all-reduces
+    float *d_grad = nullptr, *d_bnstat = nullptr;
+    float *d_vel = nullptr, *d_s2 = nullptr;  // optimiser state: momentum / first moment, second moment
+    float *d_sumsq = nullptr, *d_scratch_out = nullptr, *d_wtr = nullptr;
     Segment *d_segs = nullptr;
+    long step = 0;             // optimiser steps taken (Adam / Nadam bias corrections)
+    double m_schedule = 1.0;   // Nadam's running product of the momentum schedule
 };
 
 extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out) {
@@ -828,7 +866,8 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     t->m = m, t->max_batch = max_batch;
     const Offsets off = offsets(m);
     std::vector<Segment> segs;
-    auto add = [&](size_t o, size_t n, int kind, int aux) { segs.push_back(Segment{(unsigned)o, (unsigned)n, kind, aux}); };
+    int group = 0;
+    auto add = [&](size_t o, size_t n, int kind, int aux) { segs.push_back(Segment{(unsigned)o, (unsigned)n, kind, aux, group}); };
     add(off.w0_k, (size_t)m->cfg.n_feat * C, 0, 0);
     add(off.w0_b, C, 0, 0);
     for (int b = 0; b < m->n_blocks; ++b) {
@@ -838,9 +877,11 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
         add(w + 3 * C * C + C, C * C, 0, 0);
         add(w + 3 * C * C + C + C * C, C, 0, 0);
     }
+    group = 1;
     add(off.c3_k, (size_t)m->D * m->cfg.n_classes, 0, 0);
     add(off.c3_b, m->cfg.n_classes, 0, 0);
     for (int h = 0; h < m->n_heads; ++h) {
+        group = 2 + h;
         size_t p = off.head[h];
         add(p, (size_t)m->D * kHidden, 1, 0), p += (size_t)m->D * kHidden;
         add(p, kHidden, 0, 0), p += kHidden;                 // dense bias
@@ -857,16 +898,18 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_pre, (size_t)max_batch * kPS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_dpre, (size_t)max_batch * kPS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_dxh, (size_t)max_batch * kPS * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_grad, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_grad, (m->n_params + kMaxHeads * 32) * sizeof(float));
+    if (e == hipSuccess) t->d_bnstat = t->d_grad + m->n_params;
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_vel, m->n_params * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_bnstat, kMaxHeads * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_s2, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_sumsq, segs.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_scratch_out, (size_t)max_batch * m->out_dim * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_wtr, (size_t)m->n_blocks * 4 * C * C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Segment));
     if (e == hipSuccess) e = hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(t->d_vel, 0, m->n_params * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(t->d_grad, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(t->d_s2, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(t->d_grad, 0, (m->n_params + kMaxHeads * 32) * sizeof(float));
     if (e != hipSuccess) {
         smh_trainer_destroy(t);
         return smh::set_error(SMH_E_HIP, "smh_trainer_create: device allocation failed: %s", hipGetErrorString(e));
@@ -877,7 +920,7 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
 
 extern "C" void smh_trainer_destroy(smh_trainer *t) {
     if (!t) return;
-    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_bnstat, t->d_sumsq, t->d_scratch_out, t->d_wtr})
+    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_s2, t->d_sumsq, t->d_scratch_out, t->d_wtr})
         (void)hipFree(p);
     (void)hipFree(t->d_segs);
     delete t;
@@ -906,6 +949,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (h_loss_weights)
         for (int i = 0; i <= m->n_heads; ++i) ha.lw[i] = h_loss_weights[i];
     ha.goff_c3b = off.c3_b;
+    ha.ext_losses = 1;
     size_t hpo = 0;
     for (int i = 0; i < m->n_heads; ++i) {  // d_hp: per head [gamma, beta, mean, var, out kernel, out bias], packed
         ha.hp_off[i] = hpo;
@@ -959,18 +1003,61 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     return smh::launch_status("tcn_backward_kernel");
 }
 
-extern "C" int smh_trainer_apply_sgd_f32(smh_trainer *t, float lr, float momentum, float clipnorm, float grad_scale,
-                                         void *stream) {
-    SMH_REQUIRE(t, "smh_trainer_apply_sgd_f32: null trainer");
+extern "C" size_t smh_trainer_bucket_floats(const smh_trainer *t) { return t ? t->m->n_params + kMaxHeads * 32 : 0; }
+
+extern "C" int smh_trainer_copy_state(smh_trainer *dst, const smh_trainer *src, void *stream) {
+    SMH_REQUIRE(dst && src && dst->m == src->m, "smh_trainer_copy_state: both trainers must belong to the same model");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = dst->m->n_params * sizeof(float);
+    SMH_CHECK_HIP(hipMemcpyAsync(dst->d_vel, src->d_vel, nb, hipMemcpyDeviceToDevice, st));
+    SMH_CHECK_HIP(hipMemcpyAsync(dst->d_s2, src->d_s2, nb, hipMemcpyDeviceToDevice, st));
+    SMH_CHECK_HIP(hipStreamSynchronize(st));  // the caller destroys `src` next
+    dst->step = src->step, dst->m_schedule = src->m_schedule;
+    return SMH_OK;
+}
+
+extern "C" int smh_trainer_reset_state(smh_trainer *t, void *stream) {
+    SMH_REQUIRE(t, "smh_trainer_reset_state: null trainer");
+    hipStream_t st = (hipStream_t)stream;
+    SMH_CHECK_HIP(hipMemsetAsync(t->d_vel, 0, t->m->n_params * sizeof(float), st));
+    SMH_CHECK_HIP(hipMemsetAsync(t->d_s2, 0, t->m->n_params * sizeof(float), st));
+    t->step = 0, t->m_schedule = 1.0;
+    return SMH_OK;
+}
+
+extern "C" int smh_trainer_apply_f32(smh_trainer *t, int optimizer, float lr, float beta1, float beta2, float eps,
+                                     float clipnorm, float grad_scale, unsigned active_mask, void *stream) {
+    SMH_REQUIRE(t, "smh_trainer_apply_f32: null trainer");
+    SMH_REQUIRE(optimizer >= 0 && optimizer <= 2, "smh_trainer_apply_f32: optimizer must be 0 (SGD), 1 (Adam) or 2 (Nadam)");
     smh_model *m = t->m;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(seg_sumsq_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, m->d_flat, t->d_grad, grad_scale,
+    t->step += 1;
+    OptArgs o{};
+    o.optimizer = optimizer, o.lr = lr, o.b1 = beta1, o.b2 = beta2, o.eps = eps, o.clipnorm = clipnorm, o.grad_scale = grad_scale;
+    o.active_mask = active_mask;
+    const double tt = (double)t->step;
+    if (optimizer == 1) o.alpha = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, tt)) / (1.0 - std::pow((double)beta1, tt)));
+    if (optimizer == 2) {  // tf.keras.optimizers.Nadam (2.x): momentum schedule u_t = b1 (1 - 0.5 * 0.96^(0.004 t))
+        const double u_t = beta1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * tt));
+        const double u_t1 = beta1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (tt + 1.0)));
+        const double ms_new = t->m_schedule * u_t, ms_next = ms_new * u_t1;
+        t->m_schedule = ms_new;
+        o.n_g = (float)((1.0 - u_t) / (1.0 - ms_new));   // (1 - u_t) * g / (1 - prod u)
+        o.n_m = (float)(u_t1 / (1.0 - ms_next));         // u_{t+1} * m_t / (1 - prod u * u_{t+1})
+        o.n_v = (float)(1.0 / (1.0 - std::pow((double)beta2, tt)));
+    }
+    hipLaunchKernelGGL(seg_sumsq_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, m->d_flat, t->d_grad, grad_scale, active_mask,
                        t->d_sumsq);
     int rc = smh::launch_status("seg_sumsq_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(seg_sgd_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, m->d_flat, t->d_grad, t->d_vel, t->d_sumsq,
-                       t->d_bnstat, lr, momentum, clipnorm);
-    rc = smh::launch_status("seg_sgd_kernel");
+    hipLaunchKernelGGL(seg_opt_kernel, dim3(t->nseg), dim3(256), 0, st, t->d_segs, o, m->d_flat, (const float *)t->d_grad, t->d_vel,
+                       t->d_s2, (const float *)t->d_sumsq, (const float *)t->d_bnstat);
+    rc = smh::launch_status("seg_opt_kernel");
     if (rc) return rc;
     return repack(m, st);
+}
+
+extern "C" int smh_trainer_apply_sgd_f32(smh_trainer *t, float lr, float momentum, float clipnorm, float grad_scale,
+                                         void *stream) {
+    return smh_trainer_apply_f32(t, 0, lr, momentum, 0.f, 0.f, clipnorm, grad_scale, 0xFFFFFFFFu, stream);
 }

@@ -1,79 +1,189 @@
-"""Keras-style training surface of B3MTL: `train_on_batch`, `fit`, `evaluate`.
+"""Keras-style training surface of B3MTL: `compile`, `train_on_batch`, `fit`, `evaluate`.
 
 Mirrors how the reference drives the model (Proposed_Work_Results.py:275-312, 678-700):
-  model.fit(generator, steps_per_epoch, epochs, validation_data=generator, validation_steps,
-            callbacks=[CSVLogger, EarlyStopping(val_loss, min_delta=.01, patience=5, restore_best_weights),
-                       ModelCheckpoint(save_best_only, save_weights_only)])
+  model.fit(generator, steps_per_epoch, epochs, validation_data=generator, validation_steps, verbose=1,
+            callbacks=[CSVLogger(logFile), EarlyStopping(val_loss, min_delta=.01, patience=5, restore_best_weights),
+                       ModelCheckpoint(weightFile, save_best_only, save_weights_only)])
   model.evaluate(generator, steps) -> [loss, S_loss, M_loss, R_loss, 3C_loss, 3C_accuracy]
 with the optimiser of lib/proposed_architectures.py:156-158: SGD(ExponentialDecay(0.002, 3*TR_STEPS, 0.1),
 momentum=0.9, clipnorm=1).  All arithmetic runs in libsmh (HIP); torch supplies device memory, random
-dropout masks and -- for data parallel training -- ONE all-reduce of the flat gradient over RCCL.
+dropout masks and -- for data parallel training -- ONE all-reduce of the bucket [flat gradient | BatchNorm batch
+statistics] over RCCL.  Nothing in a step reads the device back: the losses of an epoch are summed on the device and
+copied to the host once per epoch (`train_on_batch` returns host floats, as Keras does, unless sync=False).
 """
 from __future__ import annotations
 
 import ctypes as C
-import csv
+import os
 import time
 
 import numpy as np
 import torch
 
 from . import _lib
+from . import optimizers as _opt
+from .callbacks import Callback, CSVLogger, EarlyStopping, ModelCheckpoint
 
 HEAD_DROPOUT = 0.4  # Dropout(0.4) of MTL_modifications (proposed_architectures.py:49,63,76)
 L2 = 0.01
+TRAIN_TRUNK, TRAIN_3C, TRAIN_ALL = 1, 2, 0xFFFFFFFF
+# fit() arguments of tf.keras that change nothing here (single process, generators consumed in the calling thread)
+_FIT_IGNORED = ("workers", "use_multiprocessing", "max_queue_size", "shuffle", "class_weight", "sample_weight",
+                "validation_freq", "validation_batch_size")
+_LOSS_OF = {"S": "binary_crossentropy", "M": "binary_crossentropy", "N": "binary_crossentropy", "R": "mean_squared_error",
+            "3C": "categorical_crossentropy"}
 
 
 def _cur_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class History:
+def train_head_bit(h):
+    return 4 << h
+
+
+class History(Callback):
     def __init__(self):
+        super().__init__()
         self.history = {}
         self.epoch = []
 
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+def _as_callbacks(callbacks, csv_log, checkpoint_path, early_stopping):
+    """`callbacks=[...]` as the reference passes them, plus the keyword spellings round 1 offered."""
+    cbs = list(callbacks or [])
+    for cb in cbs:
+        if not isinstance(cb, Callback):
+            raise TypeError("fit(callbacks=...): %r is not one of sm_hpss_mtl_amd.callbacks (EarlyStopping, ModelCheckpoint, "
+                            "CSVLogger or a Callback subclass)" % (cb,))
+    if csv_log:
+        cbs.append(CSVLogger(csv_log))
+    if early_stopping:
+        cbs.append(EarlyStopping(**early_stopping))
+    if checkpoint_path:
+        mon = (early_stopping or {}).get("monitor", "val_loss")
+        cbs.append(ModelCheckpoint(checkpoint_path, monitor=mon, save_best_only=True, save_weights_only=True))
+    return cbs
+
 
 class TrainingMixin:
-    """Mixed into sm_hpss_mtl_amd.model.B3MTL."""
+    """Mixed into sm_hpss_mtl_amd.model.B3MTL (and, through CnnTrainingMixin, into CnnMTL)."""
+
+    # C entry points of this model family's trainer: create, destroy, copy_state, grad_ptr, bucket_floats
+    _TRAINER_API = ("smh_trainer_create", "smh_trainer_destroy", "smh_trainer_copy_state", "smh_trainer_grad_ptr",
+                    "smh_trainer_bucket_floats")
+    _MIN_TRAINER_CAP = 64
 
     # ---- optimiser state --------------------------------------------------------------------
     def _init_training_state(self):
         self._trainer = None
         self._trainer_cap = 0
+        self._grad_view = None
         self.iterations = 0
-        self.momentum, self.clipnorm = 0.9, 1.0
-        self.decay_steps = 3 * max(int(self.TR_STEPS), 1)
-        self.decay_rate = 0.1
+        self.stop_training = False
+        # lib/proposed_architectures.py:156-158
+        self.optimizer = _opt.SGD(learning_rate=_opt.ExponentialDecay(self.initial_learning_rate, 3 * max(int(self.TR_STEPS), 1), 0.1),
+                                  clipnorm=1, momentum=0.9)
         self._rng = torch.Generator(device="cuda")
-        self._rng.manual_seed(1234)
+        self._rng.manual_seed(1234 + int(os.environ.get("RANK", "0")))  # data parallel: every rank draws its own masks
 
     def learning_rate(self, step=None):
-        """ExponentialDecay(0.002, decay_steps=3*TR_STEPS, decay_rate=0.1), not staircase."""
-        step = self.iterations if step is None else step
-        return self.initial_learning_rate * self.decay_rate ** (step / float(self.decay_steps))
+        """Learning rate of optimiser step `step` (default: the next one), e.g. ExponentialDecay(0.002, 3*TR_STEPS, 0.1)."""
+        return self.optimizer.lr_at(self.iterations if step is None else step)
+
+    # round-1 attribute names, still read by tools/ and tests
+    @property
+    def momentum(self):
+        return getattr(self.optimizer, "momentum", 0.0)
+
+    @property
+    def clipnorm(self):
+        return self.optimizer.clipnorm or 0.0
+
+    def compile(self, loss=None, optimizer=None, metrics=None, loss_weights=None, **kwargs):
+        """`model.compile(loss={...}, optimizer=optimizers.SGD(...), metrics={'3C': 'accuracy'})` as the reference calls it
+        after reloading a model (Proposed_Work_Results.py:386-441).  The losses of the MTL graph are fixed (S/M/N binary
+        cross-entropy, R mean squared error, 3C categorical cross-entropy): anything else is an error, not a silent
+        change.  `optimizer` is one of sm_hpss_mtl_amd.optimizers."""
+        if kwargs:
+            raise TypeError("compile: unsupported arguments %s" % sorted(kwargs))
+        if loss is not None:
+            if isinstance(loss, str):
+                loss = {n: loss for n in self.output_names} if len(self.output_names) == 1 else None
+                if loss is None:
+                    raise ValueError("compile: the MTL model needs one loss per output: %s" % _LOSS_OF)
+            for name, fn in loss.items():
+                if name not in self.output_names:
+                    raise ValueError("compile: unknown output %r (outputs: %s)" % (name, self.output_names))
+                if fn != _LOSS_OF[name]:
+                    raise ValueError("compile: output %r is built with %s, not %r" % (name, _LOSS_OF[name], fn))
+        if optimizer is not None:
+            if not isinstance(optimizer, _opt._Optimizer):
+                raise TypeError("compile: optimizer must be sm_hpss_mtl_amd.optimizers.SGD / Adam / Nadam, got %r" % (optimizer,))
+            self._set_optimizer(optimizer)
+        if loss_weights is not None:
+            self.loss_weights = dict(loss_weights)
+        if metrics is not None:
+            m = metrics if isinstance(metrics, dict) else {"3C": metrics}
+            for name, v in m.items():
+                vv = v if isinstance(v, str) else (v[0] if len(v) == 1 else None)
+                if name != "3C" or vv not in ("accuracy", "acc"):
+                    raise ValueError("compile: the only metric of the MTL models is {'3C': 'accuracy'}, got %r" % (metrics,))
+
+    def _set_optimizer(self, optimizer):
+        self.optimizer = optimizer
+        self.iterations = 0
+        self._reset_optimizer_state()  # a freshly compiled Keras model starts a fresh optimiser
+
+    def _reset_optimizer_state(self):
+        if self._trainer is not None:
+            _lib.check(self.lib.smh_trainer_reset_state(self._trainer, _cur_stream()), "smh_trainer_reset_state")
+
+    def _head_spec(self):
+        from .model import head_spec
+        return head_spec(self.n_classes)
+
+    def _trainer_fn(self, i):
+        return getattr(self.lib, self._TRAINER_API[i])
 
     def _get_trainer(self, n):
+        """The native trainer, grown when a batch exceeds its capacity.  Only the activation scratch depends on the
+        capacity: momentum / Adam moments / step counters are copied into the larger trainer, so a bigger batch later
+        in training never resets the optimiser."""
         if self._trainer is None or n > self._trainer_cap:
-            if self._trainer is not None:
-                self.lib.smh_trainer_destroy(self._trainer)
-            cap = max(n, 64)
+            cap = max(n, self._MIN_TRAINER_CAP)
             h = C.c_void_p()
-            _lib.check(self.lib.smh_trainer_create(self._h, cap, C.byref(h)), "smh_trainer_create")
+            _lib.check(self._trainer_fn(0)(self._h, cap, C.byref(h)), self._TRAINER_API[0])
+            if self._trainer is not None:
+                _lib.check(self._trainer_fn(2)(h, self._trainer, _cur_stream()), self._TRAINER_API[2])
+                self._trainer_fn(1)(self._trainer)
             self._trainer, self._trainer_cap = h, cap
             self._grad_view = None
+            self._on_new_trainer()
         return self._trainer
 
-    def _grad_tensor(self):
-        """torch view of the trainer's flat gradient (for the RCCL all-reduce)."""
+    def _on_new_trainer(self):
+        pass
+
+    def _bucket_tensor(self):
+        """torch view of the trainer's data-parallel bucket [flat gradient | BatchNorm batch statistics]."""
         if self._grad_view is None:
-            ptr = self.lib.smh_trainer_grad_ptr(self._trainer)
-            n = self.count_params()
+            ptr = self._trainer_fn(3)(self._trainer)
+            n = int(self._trainer_fn(4)(self._trainer))
 
             class _Holder:
                 __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
             self._grad_view = torch.as_tensor(_Holder(), device="cuda")
         return self._grad_view
+
+    def _grad_tensor(self):
+        """The flat gradient (canonical parameter order) of the last step."""
+        return self._bucket_tensor()[: self.count_params()]
 
     # ---- targets ----------------------------------------------------------------------------------
     def pack_targets(self, y):
@@ -90,16 +200,28 @@ class TrainingMixin:
             raise ValueError("targets have %d columns, model outputs %d" % (t.shape[1], self.out_dim))
         return t.cuda().contiguous()
 
-    def _loss_weight_array(self):
+    def _loss_weight_array(self, only=None):
         w = [1.0] * len(self.output_names)
         if self.loss_weights:
             for i, n in enumerate(self.output_names):
                 w[i] = float(self.loss_weights.get(n, 1.0))
+        if only is not None:  # single-output sub-model: the other outputs are not part of it
+            w = [1.0 if n == only else 0.0 for n in self.output_names]
         return (C.c_float * len(w))(*w)
 
+    def _n_losses(self):
+        return 3 * (len(self.output_names) - 1) + 4
+
+    def losses_to_list(self, raw):
+        """Raw device losses of one step (or their mean over steps) -> Keras order [loss, <per-output losses>, 3C_accuracy]."""
+        lv = raw.detach().cpu().numpy() if isinstance(raw, torch.Tensor) else np.asarray(raw)
+        nh = len(self.output_names) - 1
+        return [float(lv[nh + 1] + lv[nh + 3])] + [float(v) for v in lv[: nh + 1]] + [float(lv[nh + 2])]
+
     # ---- one step ---------------------------------------------------------------------------------
-    def train_on_batch(self, x, y, drop_tcn="auto", drop_heads="auto", apply=True):
-        """One optimiser step.  Returns [loss, <per-output losses>, 3C_accuracy] like Keras.
+    def train_on_batch(self, x, y, drop_tcn="auto", drop_heads="auto", apply=True, sync=True, _only=None, _mask=TRAIN_ALL):
+        """One optimiser step.  Returns [loss, <per-output losses>, 3C_accuracy] like Keras; with sync=False the raw
+        device tensor of the step's losses (no host round trip: feed it to `losses_to_list` later).
         drop_*: "auto" draws masks with the model's rates, None disables dropout, or pass mask tensors."""
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
@@ -108,6 +230,8 @@ class TrainingMixin:
         if x.dim() != 3 or x.shape[1] != self.patch_size or x.shape[2] != self.n_feat:
             raise ValueError("expected input (N, %d, %d), got %s" % (self.patch_size, self.n_feat, tuple(x.shape)))
         yt = y if (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() == 2) else self.pack_targets(y)
+        if yt.shape[0] != n:
+            raise ValueError("%d inputs but %d target rows" % (n, yt.shape[0]))
         self._sync_weights()
         tr = self._get_trainer(n)
         n_blocks, n_heads = self.nb_stacks * self.n_dilations, len(self.output_names) - 1
@@ -117,26 +241,31 @@ class TrainingMixin:
         if isinstance(drop_heads, str):
             keep = 1.0 - HEAD_DROPOUT
             drop_heads = (torch.rand((n, n_heads, 16), device="cuda", generator=self._rng) < keep).float() / keep
-        losses = torch.empty(n_heads + 4, dtype=torch.float32, device="cuda")
+        losses = torch.empty(self._n_losses(), dtype=torch.float32, device="cuda")
         p = lambda t: None if t is None else C.c_void_p(t.contiguous().data_ptr())  # noqa: E731
-        _lib.check(self.lib.smh_train_step_f32(tr, p(x), p(yt), n, p(drop_tcn), p(drop_heads), self._loss_weight_array(),
+        _lib.check(self.lib.smh_train_step_f32(tr, p(x), p(yt), n, p(drop_tcn), p(drop_heads), self._loss_weight_array(_only),
                                                p(losses), _cur_stream()), "smh_train_step_f32")
         if apply:
-            self.apply_gradients()
-        lv = losses.cpu().numpy()
-        reg = float(lv[n_heads + 3])  # l2 penalty of the weights this step ran with, computed on the device
-        # Keras order: total loss, one loss per output, then the metric
-        return [float(lv[n_heads + 1] + reg)] + [float(v) for v in lv[: n_heads + 1]] + [float(lv[n_heads + 2])]
+            self.apply_gradients(_mask)
+        return self.losses_to_list(losses) if sync else losses
 
-    def apply_gradients(self):
-        """All-reduce (if torch.distributed is initialised), clip, momentum update, repack."""
+    def _apply_native(self, lr, scale, mask):
+        o = self.optimizer
+        kind = {"sgd": 0, "adam": 1, "nadam": 2}[o.kind]
+        b1 = o.momentum if kind == 0 else o.beta_1
+        _lib.check(self.lib.smh_trainer_apply_f32(self._trainer, kind, lr, b1, getattr(o, "beta_2", 0.0),
+                                                  getattr(o, "epsilon", 0.0), o.clipnorm or 0.0, scale, mask, _cur_stream()),
+                   "smh_trainer_apply_f32")
+
+    def apply_gradients(self, mask=TRAIN_ALL):
+        """All-reduce the bucket [gradient | BatchNorm batch statistics] (if torch.distributed is initialised) -- SUM over
+        ranks, the 1/world factor rides in the update --, then clip (after averaging: SURVEY 8e), update, repack."""
         import torch.distributed as dist
         scale = 1.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self._grad_tensor(), op=dist.ReduceOp.SUM)  # ONE flat bucket (0.9 MB) over RCCL
+            dist.all_reduce(self._bucket_tensor(), op=dist.ReduceOp.SUM)  # ONE flat bucket (0.9 MB) over RCCL
             scale = 1.0 / dist.get_world_size()
-        _lib.check(self.lib.smh_trainer_apply_sgd_f32(self._trainer, self.learning_rate(), self.momentum, self.clipnorm, scale,
-                                                      _cur_stream()), "smh_trainer_apply_sgd_f32")
+        self._apply_native(self.learning_rate(), scale, mask)
         self.iterations += 1
         self._device_newer = True
 
@@ -165,10 +294,15 @@ class TrainingMixin:
         acc = float(np.mean(outs[-1].argmax(1) == np.asarray(yl[-1]).argmax(1)))
         return [sum(a * b for a, b in zip(lw, per)) + self._l2_penalty()] + per + [acc]
 
-    def evaluate(self, x=None, y=None, steps=None, verbose=0, **_):
+    def evaluate(self, x=None, y=None, steps=None, verbose=0, batch_size=None, **kwargs):
         """model.evaluate(generator, steps) or evaluate(x, y) -> list matching `metrics_names`."""
+        bad = [k for k in kwargs if k not in _FIT_IGNORED + ("callbacks", "return_dict")]
+        if bad or kwargs.get("return_dict"):
+            raise TypeError("evaluate: unsupported arguments %s" % sorted(bad or ["return_dict"]))
         if y is not None:
             return self._losses_inference(x, y)
+        if steps is None:
+            raise ValueError("evaluate(generator) needs steps=")
         tot, cnt = None, 0
         for _ in range(int(steps)):
             bx, by = next(x)
@@ -178,66 +312,60 @@ class TrainingMixin:
         return list(tot / max(cnt, 1))
 
     # ---- fit ------------------------------------------------------------------------------------------
-    def fit(self, x=None, y=None, steps_per_epoch=None, epochs=1, validation_data=None, validation_steps=None,
-            verbose=1, csv_log=None, checkpoint_path=None, early_stopping=None, batch_size=None, **_):
-        """Generator- or array-driven training loop.
-        early_stopping: dict(monitor='val_loss', min_delta=0.01, patience=5, restore_best_weights=True)
-        checkpoint_path: best-`val_loss` weights are saved there (ModelCheckpoint(save_best_only, weights only))
-        csv_log: per-epoch CSV like keras.callbacks.CSVLogger."""
+    def _train_step_raw(self, bx, by):
+        return self.train_on_batch(bx, by, sync=False)
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+            steps_per_epoch=None, validation_steps=None, initial_epoch=0, csv_log=None, checkpoint_path=None,
+            early_stopping=None, **kwargs):
+        """`model.fit(generator, steps_per_epoch=, validation_data=generator, validation_steps=, epochs=, verbose=,
+        callbacks=[csv_logger, es, mcp])` (Proposed_Work_Results.py:298-307), or arrays (x, y, batch_size).
+        callbacks: sm_hpss_mtl_amd.callbacks.{EarlyStopping, ModelCheckpoint, CSVLogger} (or Callback subclasses); any
+        other object, and any keyword this loop does not implement, raises instead of being dropped.
+        csv_log= / checkpoint_path= / early_stopping=dict(...) are shorthand for the same three callbacks."""
+        bad = [k for k in kwargs if k not in _FIT_IGNORED]
+        if bad:
+            raise TypeError("fit: unsupported arguments %s" % sorted(bad))
         hist = History()
+        cbs = _as_callbacks(callbacks, csv_log, checkpoint_path, early_stopping) + [hist]
         names = self.metrics_names
-        es = dict(monitor="val_loss", min_delta=0.0, patience=None, restore_best_weights=False)
-        es.update(early_stopping or {})
-        best, best_w, wait = np.inf, None, 0
-        rows = []
         arrays = y is not None
         if arrays:
             xs = np.asarray(x, np.float32)
-            yl = y if isinstance(y, (list, tuple)) else [y[k] for k in self.output_names]
+            yl = y if isinstance(y, (list, tuple)) else ([y] if isinstance(y, np.ndarray) else [y[k] for k in self.output_names])
             bs = batch_size or 32
             steps_per_epoch = steps_per_epoch or int(np.ceil(len(xs) / bs))
-        for ep in range(int(epochs)):
+        elif steps_per_epoch is None:
+            raise ValueError("fit(generator) needs steps_per_epoch=")
+        self.stop_training = False
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+        for ep in range(int(initial_epoch), int(epochs)):
             t0 = time.time()
-            agg = np.zeros(len(names))
+            acc = None  # device-side sum of the raw per-step losses: one read-back per epoch
             for s in range(int(steps_per_epoch)):
                 if arrays:
                     sl = slice((s * bs) % len(xs), (s * bs) % len(xs) + bs)
                     bx, by = xs[sl], [np.asarray(a)[sl] for a in yl]
                 else:
                     bx, by = next(x)
-                agg += np.array(self.train_on_batch(bx, by))
-            logs = {n: float(v) for n, v in zip(names, agg / max(int(steps_per_epoch), 1))}
+                raw = self._train_step_raw(bx, by)
+                acc = raw.clone() if acc is None else acc.add_(raw)
+            mean = self.losses_to_list(acc / float(max(int(steps_per_epoch), 1)))
+            logs = {n: float(v) for n, v in zip(names, mean)}
             if validation_data is not None:
                 if isinstance(validation_data, (tuple, list)) and not hasattr(validation_data, "__next__"):
                     val = self.evaluate(validation_data[0], validation_data[1])
                 else:
                     val = self.evaluate(validation_data, steps=validation_steps)
                 logs.update({"val_" + n: float(v) for n, v in zip(names, val)})
-            for k, v in logs.items():
-                hist.history.setdefault(k, []).append(v)
-            hist.epoch.append(ep)
-            rows.append(dict(epoch=ep, **logs))
             if verbose:
                 print("Epoch %d/%d - %.1fs - " % (ep + 1, epochs, time.time() - t0) + " - ".join("%s: %.4f" % kv for kv in logs.items()))
-            mon = logs.get(es["monitor"])
-            if mon is not None:
-                if mon < best - es["min_delta"]:
-                    best, wait = mon, 0
-                    if es["restore_best_weights"] or checkpoint_path:
-                        best_w = self.get_weights()
-                    if checkpoint_path:
-                        self.save_weights(checkpoint_path)
-                else:
-                    wait += 1
-                    if es["patience"] is not None and wait >= es["patience"]:
-                        if verbose:
-                            print("Early stopping at epoch %d" % (ep + 1))
-                        break
-        if es["restore_best_weights"] and best_w is not None:
-            self.set_weights(best_w)
-        if csv_log and rows:
-            with open(csv_log, "w", newline="") as f:
-                wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-                wr.writeheader()
-                wr.writerows(rows)
+            for cb in cbs:
+                cb.on_epoch_end(ep, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end()
         return hist

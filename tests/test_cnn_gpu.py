@@ -78,11 +78,11 @@ def test_reference_constructors_and_initialisers():
     assert lr == 0.0001 and model.count_params() == sum(v.size for v in oc.init_doukhan(0, 240, 68).values())
     outs = model.predict(np.random.default_rng(0).standard_normal((2, 240, 68, 1)).astype(np.float32))
     assert [o.shape for o in outs] == [(2, 1), (2, 1), (2, 2), (2, 3)] and np.allclose(outs[3].sum(1), 1, atol=1e-5)
-    assert model.optimizer == "adam" and model.learning_rate() == 0.0001  # trained in tests/test_cnn_train_gpu.py
+    assert model.optimizer.kind == "adam" and model.learning_rate() == 0.0001  # trained in tests/test_cnn_train_gpu.py
     P["Model"] = "Jang_et_al_MTL"
     jang, lr = pa.get_Jang_MTL_model(P)
     assert lr == 0.001
-    assert jang.optimizer == "adam" and jang.learning_rate() == 0.001
+    assert jang.optimizer.kind == "adam" and jang.learning_rate() == 0.001
     ref = oc.init_jang(0, 20, mel_init=True, randomize=False)
     for i in (0, 57, 119):  # Constant(mel weights) initialiser of the mel-scale kernels
         assert np.allclose(jang.weights["harm_melCl%d/kernel" % i], ref["harm_melCl%d/kernel" % i], rtol=1e-6, atol=1e-9)

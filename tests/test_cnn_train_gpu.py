@@ -180,7 +180,7 @@ def test_papakostas_sgd_update():
     from oracle import cnn_mtl_train
     H, W, N, fc = 61, 68, 6, 64
     m, w = _papakostas(H, W, fc)
-    assert m.optimizer == "sgd" and m.learning_rate(700) == pytest.approx(1e-4)
+    assert m.optimizer.kind == "sgd" and m.learning_rate(700) == pytest.approx(1e-4)
     x, y = _batch(N, H, W, 8)
     ref = cnn_mtl_train.forward_backward(x, y, w, kind="Papakostas")
     m.train_on_batch(x, y, drop=None, drop_heads=None, apply=False)
@@ -353,12 +353,13 @@ def _cnn_dp_worker(rank, world, port, q):
     for _ in range(2):
         m.train_on_batch(x[sl], {k: v[sl] for k, v in y.items()}, drop=None, drop_heads=None)
     got = m.get_weights_dict()
-    q.put((rank, {k: got[k].copy() for k in ("conv2/kernel", "bn3/gamma", "fc1/kernel", "3C/kernel", "S/out/kernel")}))
+    q.put((rank, {k: v.copy() for k, v in got.items()}))
     dist.destroy_process_group()
 
 
 def test_data_parallel_gradient_allreduce_two_ranks():
-    """SURVEY 8e for the Conv2D trainer: one all-reduce of the flat gradient per step; replicas stay bit-identical."""
+    """SURVEY 8e for the Conv2D trainer: one all-reduce per step of the bucket [flat gradient | BatchNorm batch statistics];
+    replicas stay bit-identical in EVERY tensor, the moving statistics of all BatchNorm layers included."""
     import socket
     import torch.multiprocessing as mp
     from oracle import cnn_mtl
@@ -373,6 +374,37 @@ def test_data_parallel_gradient_allreduce_two_ranks():
     res = dict(q.get(timeout=300) for _ in range(2))
     [p.join(120) for p in ps]
     w0 = cnn_mtl.init_doukhan(seed=13, H=30, W=68)
+    assert any("moving_mean" in k for k in res[0]) and any("moving_variance" in k for k in res[0])
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k          # replicas agree exactly
+    for k in ("conv2/kernel", "bn3/gamma", "fc1/kernel", "3C/kernel", "S/out/kernel", "bn2/moving_mean", "S/bn/moving_variance"):
         assert not np.array_equal(res[0][k], w0[k]), k          # and the weights moved
+
+
+def test_growing_the_cnn_trainer_keeps_adam_moments_and_step():
+    """A later, larger batch re-creates the native trainer (its activation arena is sized by the batch): the Adam moments
+    and the bias-correction step counter must carry over.  N = 24, 24, then 60 (capacity 48 -> 60) against a trainer that had
+    room for 60 from the start."""
+    x, y = _batch(60, 30, 68, 5)
+    res = []
+    for presize in (False, True):
+        m, w = _model(30, 68, seed=13)
+        if presize:
+            m._get_trainer(60)
+        for _ in range(2):
+            m.train_on_batch(x[:24], {k: v[:24] for k, v in y.items()}, drop=None, drop_heads=None)
+        m.train_on_batch(x, y, drop=None, drop_heads=None)
+        assert m._trainer_cap == 60 and m.iterations == 3
+        res.append(m.get_weights_dict())
+    for k in res[0]:
+        delta = np.abs(res[1][k] - w[k]).max()
+        assert np.abs(res[0][k] - res[1][k]).max() <= 2e-3 * delta + 1e-7, k
+    # a trainer that forgot its state restarts the bias correction at step 1: the third update would be ~lr per weight,
+    # visibly different
+    m, w = _model(30, 68, seed=13)
+    for _ in range(2):
+        m.train_on_batch(x[:24], {k: v[:24] for k, v in y.items()}, drop=None, drop_heads=None)
+    m._reset_optimizer_state()
+    m.train_on_batch(x, y, drop=None, drop_heads=None)
+    k = "conv2/kernel"
+    assert np.abs(m.get_weights_dict()[k] - res[1][k]).max() > 0.05 * np.abs(res[1][k] - w[k]).max()

@@ -76,3 +76,30 @@ def test_sgd_clipnorm_momentum_and_decay():
     nw2, nv2 = tr.sgd_step(nw, {"a/kernel": np.array([0.3, 0.4])}, nv, {"S": (np.array([0.0]), np.array([1.0]))}, lr=0.1)
     np.testing.assert_allclose(nv2["a/kernel"], 0.9 * np.array([-0.06, -0.08]) - 0.1 * np.array([0.3, 0.4]))
     assert abs(tr.exponential_decay(30, 0.002, 30, 0.1) - 0.0002) < 1e-15
+
+
+def test_adam_and_nadam_steps_vs_torch_optim():
+    """oracle adam_step / nadam_step (Keras 2.x formulas) against torch.optim on the CPU.  torch.optim.NAdam implements
+    the same Dozat momentum schedule (momentum_decay = Keras' schedule_decay = 0.004): agreement to 1e-9.  torch's Adam
+    puts epsilon outside the bias correction (sqrt(v)/sqrt(1-b2^t) + eps, Keras: sqrt(v) + eps inside the folded step
+    size), an O(eps) difference: 1e-6."""
+    import torch
+    from oracle import b3_mtl_train as tr
+    rng = np.random.default_rng(0)
+    w = {"a": rng.standard_normal(5), "b": rng.standard_normal((3, 2))}
+
+    def run(step, opt_cls, **kw):
+        w0 = {k: v.copy() for k, v in w.items()}
+        tw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w0.items()}
+        opt = opt_cls(list(tw.values()), lr=0.002, eps=1e-7, **kw)
+        st = {}
+        for _ in range(6):
+            g = {k: rng.standard_normal(v.shape) for k, v in w0.items()}
+            for k in tw:
+                tw[k].grad = torch.tensor(g[k])
+            opt.step()
+            w0, st = step(w0, g, st, 0.002)
+        return max(np.abs(w0[k] - tw[k].detach().numpy()).max() for k in w0)
+
+    assert run(tr.nadam_step, torch.optim.NAdam, momentum_decay=0.004) < 1e-9
+    assert run(tr.adam_step, torch.optim.Adam) < 1e-6

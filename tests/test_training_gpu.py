@@ -148,12 +148,18 @@ def _dp_worker(rank, world, port, q):
     for _ in range(2):
         m.train_on_batch(x[sl], yl, drop_tcn=None, drop_heads=None)
     got = m.get_weights_dict()
-    q.put((rank, {k: got[k].copy() for k in ("tcn/s0_d1/conv/kernel", "3C/kernel", "S/out/kernel", "tcn/initial_conv/bias")}))
+    seed_probe = float(torch.rand(1, device="cuda", generator=m._rng).item())  # the ranks' dropout streams must differ
+    q.put((rank, {k: v.copy() for k, v in got.items()}, seed_probe))
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradient_allreduce_two_ranks():
-    """one flat gradient all-reduce per step; replicas stay bit-identical."""
+def test_data_parallel_step_equals_the_oracle_step_on_the_mean_gradient():
+    """SURVEY 8e.  Two ranks, one shard of the batch each, ONE all-reduce per step of the bucket [flat gradient | BatchNorm
+    batch statistics].  Checked: (1) the replicas stay bit-identical in EVERY tensor, BatchNorm moving statistics
+    included; (2) after two steps the weights equal the oracle's SGD(momentum, clipnorm) update computed from the MEAN
+    of the two shard gradients, clipped AFTER averaging, with the moving statistics following the mean of the shards'
+    batch statistics -- a wrong 1/world factor or clipping before the average would fail this; (3) the ranks' dropout
+    generators are seeded differently."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -164,9 +170,210 @@ def test_data_parallel_gradient_allreduce_two_ranks():
     q = ctx.Queue()
     ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
-    res = dict(q.get(timeout=300) for _ in range(2))
+    got = [q.get(timeout=300) for _ in range(2)]
     [p.join(120) for p in ps]
-    w0 = _problem(3, 8, seed=9)[0]
+    res = {r: wts for r, wts, _ in got}
+    probes = {r: pr for r, _, pr in got}
+    assert probes[0] != probes[1]
     for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), k          # replicas agree exactly
-        assert not np.array_equal(res[0][k], w0[k]), k          # and the weights moved
+        assert np.array_equal(res[0][k], res[1][k]), k  # replicas agree exactly, */bn/moving_* too
+    # the oracle: per-shard forward/backward, mean gradient, ONE clipped momentum step; twice
+    w0, x, y, _, _ = _problem(3, 8, seed=9)
+    wd, vel = {k: v.astype(np.float64) for k, v in w0.items()}, {}
+    for step in range(2):
+        refs = [tr.forward_backward(x[sl], {k: v[sl] for k, v in y.items()}, wd, 3) for sl in (slice(0, 4), slice(4, 8))]
+        gmean = {k: 0.5 * (refs[0]["grads"][k] + refs[1]["grads"][k]) for k in refs[0]["grads"]}
+        bn = {h: tuple(0.5 * (refs[0]["bn_batch"][h][i] + refs[1]["bn_batch"][h][i]) for i in range(2)) for h in refs[0]["bn_batch"]}
+        wd, vel = tr.sgd_step(wd, gmean, vel, bn, tr.exponential_decay(step, 0.002, 30, 0.1))
+    clipped = 0
+    for k, v in wd.items():
+        delta = np.abs(v - w0[k]).max()
+        assert delta > 0, k
+        assert np.abs(res[0][k] - v).max() <= 2e-3 * delta + 1e-7, (k, np.abs(res[0][k] - v).max(), delta)
+        if not k.endswith(tr.TRAINABLE_SKIP) and np.sqrt(np.sum(gmean[k] ** 2)) > 1.0:
+            clipped += 1
+    assert clipped >= 1  # the problem does exercise clipnorm (else clip-before-average could not be told apart)
+    # and clipping each shard's gradient BEFORE averaging would give a different step: make sure the test can see it
+    wrong = {}
+    ref0 = [tr.forward_backward(x[sl], {k: v[sl] for k, v in y.items()}, w0, 3) for sl in (slice(0, 4), slice(4, 8))]
+    for k in ref0[0]["grads"]:
+        gs = []
+        for r in ref0:
+            g = r["grads"][k]
+            n = np.sqrt(np.sum(g * g))
+            gs.append(g * (1.0 / n) if n > 1.0 else g)
+        wrong[k] = 0.5 * (gs[0] + gs[1])
+    right = {k: 0.5 * (ref0[0]["grads"][k] + ref0[1]["grads"][k]) for k in wrong}
+    diff = max(np.abs(wrong[k] - right[k] * min(1.0, 1.0 / max(np.sqrt(np.sum(right[k] ** 2)), 1e-30))).max() for k in wrong)
+    assert diff > 1e-4
+
+
+@pytest.mark.parametrize("ncls,N", [(3, 510), (3, 512), (5, 510)])
+def test_gradients_and_losses_at_the_config4_batch(ncls, N):
+    """BASELINE config 4 trains with batch 512 (3 x 170 = 510 patches for the class-balanced 3-class batch; 5 x 102 = 510
+    for 5 classes).  `heads_train_kernel` is ONE workgroup whose batch reductions loop over N, the backward kernels
+    accumulate over 510 workgroups with float atomics: losses and every gradient tensor at that size against the oracle."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=21)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls)
+    m.set_weights_dict(w)
+    heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
+    got = m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda(), apply=False)
+    ref = tr.forward_backward(x, y, w, ncls, drop_tcn, {h: drop_heads[:, i] for i, h in enumerate(heads)})
+    assert abs(got[0] - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"]))
+    for i, name in enumerate(heads + ["3C"]):
+        assert abs(got[1 + i] - ref["losses"][name]) < 2e-4 * max(1.0, abs(ref["losses"][name])), name
+    assert abs(got[-1] - ref["acc"]) < 1e-6
+    g = _flat_to_dict(m, m._grad_tensor().cpu().numpy())
+    for name, gref in ref["grads"].items():
+        if name.endswith(tr.TRAINABLE_SKIP):
+            continue
+        gg = g[name].astype(np.float64)
+        if name.endswith("/dense/kernel"):
+            gg = gg + 2 * tr.L2 * w[name]
+        scale = max(np.abs(gref).max(), 1e-6)
+        assert np.abs(gg - gref).max() <= 2e-3 * scale + 1e-6, (name, np.abs(gg - gref).max(), scale)
+    # batch statistics handed to the moving averages (behind the gradient in the data-parallel bucket)
+    bn = m._bucket_tensor()[m.count_params():].cpu().numpy()
+    for hi, h in enumerate(heads):
+        mean, var = ref["bn_batch"][h]
+        assert np.abs(bn[hi * 32:hi * 32 + 16] - mean).max() <= 1e-4 * max(1.0, np.abs(mean).max())
+        assert np.abs(bn[hi * 32 + 16:hi * 32 + 32] - var).max() <= 1e-4 * max(1.0, np.abs(var).max())
+
+
+def test_growing_the_trainer_keeps_the_optimiser_state():
+    """A batch larger than the trainer's capacity re-creates the native trainer: momentum must survive.  Step at N = 48, then
+    at N = 96 (capacity 64 -> 96) against a model whose trainer had room for 96 from the start."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, _, _ = _problem(3, 96, seed=13)
+    res = []
+    for presize in (False, True):
+        m = B3MTL(n_feat=240, patch_size=68, n_classes=3, TR_STEPS=10)
+        m.set_weights_dict(w)
+        if presize:
+            m._get_trainer(96)
+        small = {k: v[:48] for k, v in y.items()}
+        for _ in range(2):
+            m.train_on_batch(x[:48], small, drop_tcn=None, drop_heads=None)
+        cap_before = m._trainer_cap
+        m.train_on_batch(x, y, drop_tcn=None, drop_heads=None)
+        assert m._trainer_cap == 96 and (presize or cap_before == 64)
+        res.append(m.get_weights_dict())
+    for k in res[0]:
+        delta = np.abs(res[1][k] - w[k]).max()
+        # same arithmetic either way; only the order of the float atomics in the weight gradients differs run to run
+        assert np.abs(res[0][k] - res[1][k]).max() <= 1e-3 * delta + 1e-7, k
+    # and momentum really was there: a fresh optimiser on the third step gives a visibly different update
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=3, TR_STEPS=10)
+    m.set_weights_dict(w)
+    for _ in range(2):
+        m.train_on_batch(x[:48], {k: v[:48] for k, v in y.items()}, drop_tcn=None, drop_heads=None)
+    m._reset_optimizer_state()
+    m.train_on_batch(x, y, drop_tcn=None, drop_heads=None)
+    k = "tcn/s0_d1/conv/kernel"
+    assert np.abs(m.get_weights_dict()[k] - res[1][k]).max() > 0.05 * np.abs(res[1][k] - w[k]).max()
+
+
+def test_fit_with_the_reference_callbacks_and_compile(tmp_path):
+    """The literal sequence of Proposed_Work_Results.py:275-307 + :370-374 + :376-397 on the real model: callbacks objects,
+    save / to_json / reload / compile."""
+    from sm_hpss_mtl_amd import optimizers
+    from sm_hpss_mtl_amd.callbacks import CSVLogger, EarlyStopping, ModelCheckpoint
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model, model_from_json
+    rng = np.random.default_rng(0)
+    model, learning_rate = get_Lemaire_MTL_model(TR_STEPS=4, N_MELS=240, n_classes=3, patch_size=68, loss_weights=None, seed=1)
+
+    def generator(n=24):
+        while True:
+            cls = rng.integers(0, 3, n)
+            x = rng.standard_normal((n, 68, 240)) * 0.3 + (cls[:, None, None] - 1.0) * 0.8  # float64, as the reference yields
+            yield x, {"R": np.stack([(cls != 1), (cls != 0)], 1).astype(np.float64), "S": (cls == 1).astype(np.int64),
+                      "M": (cls == 0).astype(np.int64), "3C": np.eye(3)[cls]}
+    weightFile, logFile = str(tmp_path / "m.h5"), str(tmp_path / "m_log.csv")
+    es = EarlyStopping(monitor='val_loss', mode='auto', verbose=1, restore_best_weights=True, min_delta=0.01, patience=5)
+    mcp = ModelCheckpoint(weightFile, monitor='val_loss', verbose=0, save_best_only=True, save_weights_only=True, mode='auto', save_freq='epoch')
+    csv_logger = CSVLogger(logFile)
+    History = model.fit(generator(), steps_per_epoch=4, validation_data=generator(), validation_steps=2, epochs=3, verbose=1,
+                        callbacks=[csv_logger, es, mcp])
+    assert len(History.history["val_loss"]) == 3 and model.iterations == 12
+    assert (tmp_path / "m.h5").exists() and sum(1 for _ in open(logFile)) == 4
+    with pytest.raises(TypeError):
+        model.fit(generator(), steps_per_epoch=1, epochs=1, callbacks=[lambda: None])
+    with pytest.raises(TypeError):
+        model.fit(generator(), steps_per_epoch=1, epochs=1, sample_weights=[1])
+    model.save_weights(weightFile)
+    arch = str(tmp_path / "m.json")
+    open(arch, "w").write(model.to_json())
+    with open(arch) as f:
+        model2 = model_from_json(f.read())
+    model2.load_weights(weightFile)
+    lr_schedule = optimizers.ExponentialDecay(0.002, decay_steps=1, decay_rate=0.1)
+    model2.compile(loss={'R': 'mean_squared_error', 'S': 'binary_crossentropy', 'M': 'binary_crossentropy', '3C': 'categorical_crossentropy'},
+                   optimizer=optimizers.SGD(learning_rate=lr_schedule, clipnorm=1, momentum=0.9), metrics={'3C': 'accuracy'})
+    assert model2.learning_rate(1) == pytest.approx(0.0002) and model2.iterations == 0
+    xv, yv = next(generator(12))
+    for a, b in zip(model.predict(xv), model2.predict(xv)):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        model2.compile(loss={'R': 'binary_crossentropy'})
+    with pytest.raises(TypeError):
+        model2.compile(optimizer="adam")
+
+
+def test_single_head_sub_model_nadam_fine_tuning(tmp_path):
+    """DAFx12_Speech_Music_Detection_B3_MTL_v2.py:518-526: Model(input, get_layer('M').output), Nadam(0.002), binary
+    cross-entropy, 'accuracy'.  Two steps against the oracle: loss = BCE(M) + the l2 penalty of M's Dense(16) kernel;
+    the trunk and head M follow the oracle's Nadam update of the masked-loss gradients; every other tensor is untouched."""
+    from sm_hpss_mtl_amd import optimizers
+    from sm_hpss_mtl_amd.lib.proposed_architectures import Model, model_from_json
+    from sm_hpss_mtl_amd.model import B3MTL
+    ncls, N = 3, 12
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=17)
+    trained_model = B3MTL(n_feat=240, patch_size=68, n_classes=ncls)
+    trained_model.set_weights_dict(w)
+    mu_output = trained_model.get_layer('M').output
+    model = Model(trained_model.input, mu_output)
+    with pytest.raises(RuntimeError):
+        model.train_on_batch(x, y["M"])
+    model.compile(loss='binary_crossentropy', optimizer=optimizers.Nadam(learning_rate=0.002), metrics='accuracy')
+    assert model.metrics_names == ["loss", "accuracy"]
+    heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
+    own = [k for k in w if (k.startswith("tcn/") or k.startswith("M/")) and not k.endswith(tr.TRAINABLE_SKIP)]
+    wd, st = {k: v.astype(np.float64) for k, v in w.items()}, {}
+    lw = {"S": 0.0, "M": 1.0, "R": 0.0, "3C": 0.0}
+    for step in range(2):
+        got = model.train_on_batch(x, y["M"], drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda())
+        ref = tr.forward_backward(x, y, wd, ncls, drop_tcn, {h: drop_heads[:, i] for i, h in enumerate(heads)}, lw)
+        l2_m = tr.L2 * float(np.sum(wd["M/dense/kernel"] ** 2))
+        assert abs(got[0] - (ref["losses"]["M"] + l2_m)) < 2e-4 * max(1.0, ref["losses"]["M"] + l2_m)
+        acc = float(np.mean((ref["outputs"]["M"] > 0.5) == (y["M"] > 0.5)))
+        assert abs(got[1] - acc) < 1e-6
+        grads = dict(ref["grads"])
+        new_w, st = tr.nadam_step(wd, grads, st, 0.002, names=own)
+        mean, var = ref["bn_batch"]["M"]
+        new_w["M/bn/moving_mean"] = tr.BN_MOMENTUM * wd["M/bn/moving_mean"] + (1 - tr.BN_MOMENTUM) * mean
+        new_w["M/bn/moving_variance"] = tr.BN_MOMENTUM * wd["M/bn/moving_variance"] + (1 - tr.BN_MOMENTUM) * var
+        wd = new_w
+    res = trained_model.get_weights_dict()
+    for k in w:
+        if k in own or k.startswith("M/bn/moving"):
+            delta = np.abs(wd[k] - w[k]).max()
+            assert delta > 0 and np.abs(res[k] - wd[k]).max() <= 5e-3 * delta + 1e-7, (k, np.abs(res[k] - wd[k]).max(), delta)
+        else:
+            assert np.array_equal(res[k], w[k]), k  # not part of the sub-model: untouched
+    # the driver's persistence of the sub-model (:551-552, 566-567) and its fit with the resume-by-log-lines CSV
+    from sm_hpss_mtl_amd.callbacks import CSVLogger
+    model.save_weights(str(tmp_path / "upd.h5"))
+    open(tmp_path / "upd.json", "w").write(model.to_json())
+    model2 = model_from_json(open(tmp_path / "upd.json").read())
+    model2.load_weights(str(tmp_path / "upd.h5"))
+    np.testing.assert_allclose(model2.predict(x), model.predict(x), atol=1e-6)
+
+    def gen():
+        while True:
+            yield x, y["M"]
+    h = model.fit(gen(), steps_per_epoch=3, epochs=2, verbose=0, validation_data=gen(), validation_steps=1,
+                  callbacks=[CSVLogger(str(tmp_path / "upd_log.csv"))])
+    assert set(h.history) == {"loss", "accuracy", "val_loss", "val_accuracy"} and h.history["loss"][-1] < h.history["loss"][0]
+    ev = model.evaluate(x, y["M"])
+    assert len(ev) == 2 and 0.0 <= ev[1] <= 1.0
