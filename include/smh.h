@@ -144,6 +144,20 @@ int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samp
                      float *d_patches, void *d_work, size_t work_bytes, float *d_S, float *d_harm, float *d_perc,
                      void *stream);
 
+/* ---- ragged batches: B clips of DIFFERENT lengths in one call (the reference's generators take whole files of any length
+ * one at a time: Proposed_Work_Results.py:92-95, 131-134, 189-192, 465-474).  d_audio holds the clips at sample offsets
+ * h_offsets[b] with h_lengths[b] samples each (HOST arrays; keep every offset a multiple of 2 samples = 8 bytes so that each
+ * clip takes the same kernels as in smh_frontend_f32 and gets the same bits).  Consecutive clips of equal length lying back
+ * to back are batched into one launch set.  Outputs are concatenated: clip b's featuregram (2*rows, T_b) starts at float
+ * h_fv_off[b] of d_fv, its nP_b standardised time-major patches at patch h_patch_off[b] of d_patches ((W, 2*rows) each).
+ * smh_frontend_ragged_sizes fills the per-clip tables (each may be NULL) and the workspace requirement; W <= 0: no patches. */
+int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_offsets, const int *h_lengths, int B, int W, int shift,
+                              long long *h_fv_off /* B+1 */, long long *h_patch_off /* B+1 */, int *h_T /* B */,
+                              int *h_nP /* B */, size_t *work_bytes);
+int smh_frontend_ragged_f32(const smh_ctx *ctx, const float *d_audio, const long long *h_offsets, const int *h_lengths, int B,
+                            int W, int shift, float *d_fv, float *d_patches /* or NULL */, void *d_work, size_t work_bytes,
+                            void *stream);
+
 /* ---- 8f rank 1: load_and_preprocess_signal after the decode (lib/preprocessing.py:330-350) ------------------
  * Batched over B clips of N samples each, resident on the device.  Floating point: the mean is accumulated in
  * f64 in a fixed order (numpy: pairwise f32), everything else is the same f32 arithmetic as numpy.           */

@@ -58,6 +58,9 @@ SIGNATURES = {
     "smh_features_ex_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp, _vp]),
     "smh_frontend_workspace_bytes": (_sz, [_vp, _i, _i]),
     "smh_frontend_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _fp, _fp, _fp, _vp]),
+    "smh_frontend_ragged_sizes": (_i, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_longlong),
+                                       C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "smh_frontend_ragged_f32": (_i, [_vp, _fp, C.POINTER(C.c_longlong), C.POINTER(C.c_int), _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_normalize_workspace_bytes": (_sz, [_i, _i]),
     "smh_silence_workspace_bytes": (_sz, [_i, _i, _i]),
     "smh_normalize_f32": (_i, [_fp, _i, _i, _fp, _vp, _sz, _vp]),

@@ -22,7 +22,9 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # a value loaded from LDS is preceded by a canonicalising v_max_f32 (IEEE mode), +30 % VALU in that kernel.
 # smh_train: the weight-gradient accumulation uses float atomicAdd on device memory; without the flag hipcc emits a
 # compare-and-swap loop per atomic instead of global_atomic_add_f32 (the backward kernel was 8.6 ms because of it).
-EXTRA_FLAGS = {"smh_median_split.hip": ["-fno-honor-nans"], "smh_train.hip": ["-munsafe-fp-atomics"]}
+# smh_tcn: relu / channel maximum of accumulator values; same canonicalisation issue (16 extra v_max per 16-frame tile).
+EXTRA_FLAGS = {"smh_median_split.hip": ["-fno-honor-nans"], "smh_train.hip": ["-munsafe-fp-atomics"],
+               "smh_tcn.hip": ["-fno-honor-nans"]}
 
 
 def _sources():

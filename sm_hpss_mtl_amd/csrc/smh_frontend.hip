@@ -3,7 +3,9 @@
 //   stft -> hpss medians -> soft masks -> mel -> power_to_db -> [featuregram]
 //        -> tile-if-short -> StandardScaler per half -> extract_patches -> transpose to (N, W, F).
 // Four launches, all on the caller's stream, no host synchronisation (hipGraph-capturable).
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "smh_common.h"
 #include "smh_feat.h"
@@ -139,4 +141,85 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
                                     nP > 0 ? d_patches : nullptr, st);
     if (rc) return rc;
     return nP;
+}
+
+// ---- ragged batches: clips of different lengths in one call (the reference's generators process whole files of any length
+// one by one: Proposed_Work_Results.py:92-95, 131-134, 189-192, 465-474) -------------------------------------------------------
+// Host-side orchestration over the batched kernels above: consecutive clips of the same length that lie back to back in the
+// audio buffer are one launch set, every other clip is a launch set of its own, all on the caller's stream.  Kernel choice
+// depends on (length, pointer alignment) exactly as for smh_frontend_f32, so with 8-byte aligned clip starts every clip gets
+// bit for bit what smh_frontend_f32 gives it alone or inside an equal-length batch.
+namespace {
+struct RaggedPlan {
+    std::vector<int> T, nP;
+    std::vector<long long> fv_off, patch_off;  // floats / patches in front of clip b
+    size_t work = 0;
+};
+int plan_ragged(const smh_ctx *ctx, const long long *off, const int *len, int B, int W, int shift, bool patches, RaggedPlan &p) {
+    p.T.assign(B, 0), p.nP.assign(B, 0), p.fv_off.assign(B + 1, 0), p.patch_off.assign(B + 1, 0);
+    const int rows2 = 2 * ctx->feat_rows;
+    for (int b = 0; b < B; ++b) {
+        SMH_REQUIRE(off[b] >= 0 && len[b] >= 0, "ragged: clip %d has a negative offset or length", b);
+        const int T = smh_num_frames(len[b], ctx->cfg.n_fft, ctx->cfg.hop);
+        SMH_REQUIRE(T >= 1, "ragged: clip %d of %d samples is shorter than n_fft=%d", b, len[b], ctx->cfg.n_fft);
+        p.T[b] = T;
+        p.nP[b] = patches ? smh_num_patches(smh_tiled_frames(T, W), W, shift) : 0;
+        p.fv_off[b + 1] = p.fv_off[b] + (long long)rows2 * T;
+        p.patch_off[b + 1] = p.patch_off[b] + p.nP[b];
+    }
+    return SMH_OK;
+}
+// clips b .. e-1 form one launch set: same length, back to back
+int run_end(const long long *off, const int *len, int B, int b) {
+    int e = b + 1;
+    while (e < B && len[e] == len[b] && off[e] == off[e - 1] + len[b] && e - b < 65535) ++e;
+    return e;
+}
+}  // namespace
+
+extern "C" int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_offsets, const int *h_lengths, int B, int W,
+                                         int shift, long long *h_fv_off, long long *h_patch_off, int *h_T, int *h_nP,
+                                         size_t *work_bytes) {
+    SMH_REQUIRE(ctx && (B == 0 || (h_offsets && h_lengths)) && B >= 0, "smh_frontend_ragged_sizes: bad argument");
+    SMH_REQUIRE(W <= 0 || shift >= 1, "smh_frontend_ragged_sizes: bad patch geometry W=%d shift=%d", W, shift);
+    RaggedPlan p;
+    int rc = plan_ragged(ctx, h_offsets, h_lengths, B, W, shift, W > 0, p);
+    if (rc) return rc;
+    size_t work = 0;
+    for (int b = 0; b < B;) {
+        const int e = run_end(h_offsets, h_lengths, B, b);
+        work = std::max(work, smh_frontend_workspace_bytes(ctx, e - b, h_lengths[b]));
+        b = e;
+    }
+    for (int b = 0; b <= B; ++b) {
+        if (h_fv_off) h_fv_off[b] = p.fv_off[b];
+        if (h_patch_off) h_patch_off[b] = p.patch_off[b];
+    }
+    for (int b = 0; b < B; ++b) {
+        if (h_T) h_T[b] = p.T[b];
+        if (h_nP) h_nP[b] = p.nP[b];
+    }
+    if (work_bytes) *work_bytes = work;
+    return SMH_OK;
+}
+
+extern "C" int smh_frontend_ragged_f32(const smh_ctx *ctx, const float *d_audio, const long long *h_offsets,
+                                       const int *h_lengths, int B, int W, int shift, float *d_fv, float *d_patches,
+                                       void *d_work, size_t work_bytes, void *stream) {
+    SMH_REQUIRE(ctx && d_audio && d_fv && d_work && h_offsets && h_lengths && B >= 0, "smh_frontend_ragged_f32: bad argument");
+    const bool patches = d_patches != nullptr;
+    SMH_REQUIRE(!patches || (W >= 1 && shift >= 1), "smh_frontend_ragged_f32: bad patch geometry W=%d shift=%d", W, shift);
+    RaggedPlan p;
+    int rc = plan_ragged(ctx, h_offsets, h_lengths, B, W, shift, patches, p);
+    if (rc) return rc;
+    const size_t prow = (size_t)W * 2 * ctx->feat_rows;
+    for (int b = 0; b < B;) {
+        const int e = run_end(h_offsets, h_lengths, B, b);
+        float *pt = patches && p.nP[b] > 0 ? d_patches + (size_t)p.patch_off[b] * prow : nullptr;
+        rc = smh_frontend_f32(ctx, d_audio + h_offsets[b], e - b, h_lengths[b], pt ? W : 0, pt ? shift : 0, d_fv + p.fv_off[b], pt,
+                              d_work, work_bytes, nullptr, nullptr, nullptr, stream);
+        if (rc < 0) return rc;
+        b = e;
+    }
+    return SMH_OK;
 }

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "smh_model.h"
@@ -48,7 +49,6 @@ __device__ __forceinline__ float quad_max(float v) {
     return fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
 }
 
-constexpr bool kRotate = false;  // with 9 waves the light wave must stay on the SIMD that hosts three of them
 
 struct BlockW {
     float wc[24][2], wp[8][2];
@@ -59,54 +59,124 @@ struct BlockW {
 // needs the whole block, so the 16.6 KB come from L2 once per workgroup instead of once per wave.  Packed order
 // (pack_weights below): operand slot n = 2 s + mt (dilated conv, s < 24) or 48 + 2 e + mt (1x1 conv, e < 8) of lane l
 // sits at [(n / 4) * 256 + 4 l + n % 4], so one ds_read_b128 per lane delivers four slots, conflict-free.
-__device__ __forceinline__ void load_block_lds(BlockW &w, const float *wblk, int lane, int q) {
+// the 20 ds_read_b128 of a block, numbered: 0..11 dilated-conv operand groups, 12..15 1x1-conv groups, 16..19 the biases
+template <int G0, int G1>
+__device__ __forceinline__ void load_block_part(BlockW &w, const float *wblk, int lane, int q) {
     const f32x4 *wv = reinterpret_cast<const f32x4 *>(wblk) + lane;
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-        const f32x4 v = wv[g * 64];
-        w.wc[2 * g][0] = v[0], w.wc[2 * g][1] = v[1], w.wc[2 * g + 1][0] = v[2], w.wc[2 * g + 1][1] = v[3];
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 v = wv[(12 + g) * 64];
-        w.wp[2 * g][0] = v[0], w.wp[2 * g][1] = v[1], w.wp[2 * g + 1][0] = v[2], w.wp[2 * g + 1][1] = v[3];
-    }
     const float *b1 = wblk + 24 * 2 * 64 + 8 * 2 * 64;
-    w.b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
-    w.b1hi = *reinterpret_cast<const f32x4 *>(b1 + 16 + 4 * q);
-    w.b2lo = *reinterpret_cast<const f32x4 *>(b1 + 32 + 4 * q);
-    w.b2hi = *reinterpret_cast<const f32x4 *>(b1 + 48 + 4 * q);
+#pragma unroll
+    for (int g = G0; g < G1; ++g) {
+        if (g < 12) {
+            const f32x4 v = wv[g * 64];
+            w.wc[2 * g][0] = v[0], w.wc[2 * g][1] = v[1], w.wc[2 * g + 1][0] = v[2], w.wc[2 * g + 1][1] = v[3];
+        } else if (g < 16) {
+            const f32x4 v = wv[g * 64];
+            const int h = g - 12;
+            w.wp[2 * h][0] = v[0], w.wp[2 * h][1] = v[1], w.wp[2 * h + 1][0] = v[2], w.wp[2 * h + 1][1] = v[3];
+        } else if (g == 16) {
+            w.b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
+        } else if (g == 17) {
+            w.b1hi = *reinterpret_cast<const f32x4 *>(b1 + 16 + 4 * q);
+        } else if (g == 18) {
+            w.b2lo = *reinterpret_cast<const f32x4 *>(b1 + 32 + 4 * q);
+        } else {
+            w.b2hi = *reinterpret_cast<const f32x4 *>(b1 + 48 + 4 * q);
+        }
+    }
+}
+__device__ __forceinline__ void load_block_lds(BlockW &w, const float *wblk, int lane, int q) {
+    load_block_part<0, 20>(w, wblk, lane, q);
 }
 
-// one residual block for this wave's column tiles ("units" of 16 time steps)
+// Per-wave column tiles ("units" of 16 time steps), fixed for the whole kernel: row of this lane, its frame index inside
+// the patch (the dilated taps are valid while 0 <= t + off < T) and its patch (dropout masks).
+constexpr int kMaxTiles = 4;  // 32 tiles (512-frame patches) over 8 waves
+struct TileInfo {
+    int R[kMaxTiles];   // row 16 u + j (may lie past the last live row of a partial tile: then Rc = last row)
+    int t[kMaxTiles];   // frame index of row min(R, GR - 1) inside its patch
+    int g[kMaxTiles];   // its patch inside the workgroup (SpatialDropout1D masks, training only)
+    int n;              // tiles of this wave
+};
+
+// Prefetch of the NEXT block's weights (LDS -> the other register set) in four chunks of five ds_read_b128, issued at
+// fixed points of the tile loop ("slots": 2 i = behind the operand reads of tile i, 2 i + 1 = behind its dilated-conv
+// products).  LDS returns in order and the wait counter holds 15: with at most 8 operand reads + 5 weight reads in
+// flight the compiler can wait for exactly the operands and let the weights stream in behind the products; all 20 reads
+// in one place would stand between the barrier and the first product, like loading them at the top of the block.
+struct NoPrefetch {
+    template <int SLOT>
+    __device__ __forceinline__ void slot() const {}
+    __device__ __forceinline__ void rest(int) const {}
+};
+struct WeightPrefetch {  // behind the last block the reads still run (they fetch the other slot's stale block, unused)
+    BlockW &w;
+    const float *wblk;
+    int lane, q;
+    template <int SLOT>
+    __device__ __forceinline__ void slot() const {
+        if constexpr (SLOT < 4) load_block_part<5 * SLOT, 5 * SLOT + 5>(w, wblk, lane, q);
+    }
+    // chunks whose slot this wave never reached (it owns fewer than two tiles)
+    __device__ __forceinline__ void rest(int tiles) const {
+        if (tiles < 2) {
+            if (tiles < 1) load_block_part<0, 10>(w, wblk, lane, q);
+            load_block_part<10, 20>(w, wblk, lane, q);
+        }
+    }
+};
+
+// one residual block for this wave's column tiles
 // drop: SpatialDropout1D masks of this block for the workgroup's first patch, (n, blk) stride dstride
-template <bool TRAIN>
-__device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR, int units, int wave, int nw, int q,
-                                          int j, const float *__restrict__ xin, float *__restrict__ xout,
-                                          const float *__restrict__ drop, int dstride) {
+// ZR: index of the all-zero row behind the activation rows (padding taps read it instead of masking every operand)
+// prefetch: see WeightPrefetch
+template <bool TRAIN, class PF>
+__device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
+                                          const float *__restrict__ xin, float *__restrict__ xout,
+                                          const float *__restrict__ drop, int dstride, PF prefetch) {
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
-    for (int u = wave; u < units; u += nw) {
-        const int R = 16 * u + j;
+    auto tile = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int R = ti.R[i];
         const int Rc = min(R, GR - 1);
-        const int t = Rc % T;
-        f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
-        // dilated conv: k index = tap*32 + c, step s covers c = (4s % 32) + q of tap s/8
+        const int t = ti.t[i];
+        // all LDS operands of the tile up front: 3 taps x 8 channels of this lane's k slice (k index = tap*32 + c; MFMA
+        // step s8 of a tap takes channel c = 8 q + s8 from lane group q, so a lane's eight B operands are contiguous in
+        // its activation row: two ds_read_b128 per tap), then the residual row
+        f32x4 b[3][2];
+        bool any_tap[3];
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
-            if (tap != 1 && !side_taps) continue;
             const int off = (tap - 1) * d;
-            const bool ok = (t + off >= 0) && (t + off < T);
-            if (tap != 1 && !__any(ok)) continue;  // every row of this tile reads zero padding through this tap
-            const float *src = xin + (size_t)(ok ? Rc + off : Rc) * SX + q;
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
-                float bv = src[4 * s8];
-                bv = ok ? bv : 0.f;
-                acc0 = mfma4(w.wc[tap * 8 + s8][0], bv, acc0);
-                acc1 = mfma4(w.wc[tap * 8 + s8][1], bv, acc1);
-            }
+            const bool ok = (tap == 1) || (side_taps && (t + off >= 0) && (t + off < T));
+            any_tap[tap] = (tap == 1) || (side_taps && __any(ok));  // wave-uniform: no row of the tile is live through this tap
+            // the reads are issued on every path (a dead tap reads the zero row): with a path-independent number of LDS
+            // operations in flight the compiler can wait for exactly the operands a product needs
+            const float *src = xin + (size_t)(ok ? Rc + off : ZR) * SX + 8 * q;
+            b[tap][0] = *reinterpret_cast<const f32x4 *>(src);
+            b[tap][1] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
-        // relu + channel-max normalisation ('norm_relu')
+        const float *res = xin + (size_t)Rc * SX + 4 * q;
+        f32x4 o0 = *reinterpret_cast<const f32x4 *>(res);
+        f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch.template slot<2 * i>();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            if (!any_tap[tap]) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    acc0 = mfma4(w.wc[tap * 8 + 4 * h + s4][0], b[tap][h][s4], acc0);
+                    acc1 = mfma4(w.wc[tap * 8 + 4 * h + s4][1], b[tap][h][s4], acc1);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch.template slot<2 * i + 1>();
+        __builtin_amdgcn_sched_barrier(0);
+        // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -115,19 +185,17 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
             mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
         }
         mx = quad_max(mx);
-        const float inv = 1.0f / (mx + kNormEps);
+        const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
         f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
         if constexpr (TRAIN) {
             if (drop) {
-                const float *dp = drop + (size_t)(Rc / T) * dstride + 4 * q;
+                const float *dp = drop + (size_t)ti.g[i] * dstride + 4 * q;
                 dm0 = *reinterpret_cast<const f32x4 *>(dp);
                 dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
             }
         }
         // 1x1 conv on the normalised activations + bias + residual, all from registers
-        const float *res = xin + (size_t)Rc * SX + 4 * q;
-        f32x4 o0 = *reinterpret_cast<const f32x4 *>(res) + w.b2lo;
-        f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16) + w.b2hi;
+        o0 += w.b2lo, o1 += w.b2hi;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float y0 = acc0[r] * inv * dm0[r];  // channel 4q + r
@@ -143,11 +211,17 @@ __device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR,
         float *dst = xout + (size_t)R * SX + 4 * q;
         *reinterpret_cast<f32x4 *>(dst) = o0;
         *reinterpret_cast<f32x4 *>(dst + 16) = o1;
-    }
+    };
+    static_assert(kMaxTiles == 4, "tile list below");
+    if (ti.n > 0) tile(std::integral_constant<int, 0>{});  // wave-uniform
+    if (ti.n > 1) tile(std::integral_constant<int, 1>{});
+    if (ti.n > 2) tile(std::integral_constant<int, 2>{});
+    if (ti.n > 3) tile(std::integral_constant<int, 3>{});
+    prefetch.rest(ti.n);
 }
 
-template <bool TRAIN>
-__global__ void __launch_bounds__(768)
+template <bool TRAIN, bool PREFETCH>
+__global__ void __launch_bounds__(PREFETCH ? 512 : 768)
 b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
                      const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
                      float *__restrict__ out, TrainIO tio) {
@@ -159,7 +233,8 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     const int T = a.T;
     const int GR = g_here * T;
     const int units = (GR + 15) >> 4;
-    float *xa = lds, *xb = lds + (size_t)a.GRP * SX;
+    const int ZR = a.GRP;  // all-zero row behind the GRP activation rows of each buffer (padding taps of the dilated conv)
+    float *xa = lds, *xb = lds + (size_t)(a.GRP + 1) * SX;
 
     // ---- initial Conv1D(32, 1): K order f = q*FQ + s so that every lane streams a contiguous run ----
     // Layer 0 is an HBM stream (261 KB of X per workgroup): every lane issues ALL loads of its column
@@ -235,7 +310,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
 
     // ---- residual blocks.  Block weights: global -> LDS by LDS-DMA one block ahead (two LDS slots), LDS -> registers
     // at the top of the block ----
-    float *ws = lds + 2 * (size_t)a.GRP * SX;
+    float *ws = lds + 2 * (size_t)(a.GRP + 1) * SX;
     auto stage = [&](int blk) {
         const char *src = reinterpret_cast<const char *>(Wb + (size_t)blk * kBlockFloats);
         char *dst = reinterpret_cast<char *>(ws + (size_t)(blk & 1) * kBlockFloats);
@@ -247,8 +322,17 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                                                  (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
         }
     };
-    if (a.wlds) stage(0);
-    BlockW w;
+    // this wave's column tiles and the zero rows
+    TileInfo ti;
+    ti.n = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxTiles; ++i) {
+        const int u = wave + i * nw;
+        const int R = 16 * u + j, Rc = min(R, GR - 1);
+        ti.R[i] = R, ti.g[i] = Rc / T, ti.t[i] = Rc - ti.g[i] * T;
+        if (u < units) ti.n = i + 1;
+    }
+    if (threadIdx.x < SX) xa[(size_t)ZR * SX + threadIdx.x] = 0.f, xb[(size_t)ZR * SX + threadIdx.x] = 0.f;
     float *xin = xa, *xout = xb;
     const int nslot = a.n_blocks + 1;
     auto save_acts = [&](const float *src, int slot) {  // block input -> acts[n][slot][t][c]
@@ -263,26 +347,53 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     };
     const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
     const int dstride = a.n_blocks * C;
-    for (int blk = 0; blk < a.n_blocks; ++blk) {
-        if (a.wlds) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
-            __syncthreads();                                  // xin complete, every wave's share has landed
-            load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
-            // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
-            if (blk + 1 < a.n_blocks) stage(blk + 1);
-        } else {  // very long patches: no LDS left for the weight slots, every wave reads the block from L2
-            __syncthreads();
-            load_block_lds(w, Wb + (size_t)blk * kBlockFloats, lane, q);
-        }
+    auto one_block = [&](int blk, const BlockW &w, auto prefetch) {
         save_acts(xin, blk);
-        // the wave that gets the odd unit out rotates with the block and the workgroup, so that over time (and across
-        // the workgroups sharing a CU) every SIMD carries the same load
-        const int rot = kRotate ? (int)blockIdx.x + blk : 0;
-        run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, units, (wave + rot) % nw, nw, q, j, xin, xout,
-                         drop0 ? drop0 + (size_t)blk * C : nullptr, dstride);
+        run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, ZR, ti, q, xin, xout, drop0 ? drop0 + (size_t)blk * C : nullptr, dstride,
+                         prefetch);
         float *tmp = xin;
         xin = xout;
         xout = tmp;
+    };
+    if (a.wlds && PREFETCH) {
+        // Two register sets: while block b runs from one, the weights of block b + 1 travel LDS -> registers into the other
+        // (the 20 ds_read_b128 per wave of a block -- 150 KB of LDS reads per workgroup -- no longer stand between the
+        // barrier and the first product).  LDS slot (b & 1) is refilled by LDS-DMA with block b + 2 as soon as every wave
+        // holds block b in registers, i.e. right behind the barrier at the top of block b.
+        BlockW w0, w1;
+        stage(0);
+        if (a.n_blocks > 1) stage(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_block_lds(w0, ws, lane, q);
+        for (int blk = 0; blk < a.n_blocks; blk += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk + 1 has landed
+            __syncthreads();                                  // xin complete; block blk + 1 complete in its slot; slot (blk & 1) consumed
+            if (blk + 2 < a.n_blocks) stage(blk + 2);
+            const bool more1 = blk + 1 < a.n_blocks;
+            one_block(blk, w0, WeightPrefetch{w1, ws + kBlockFloats, lane, q});
+            if (!more1) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (blk + 3 < a.n_blocks) stage(blk + 3);
+            one_block(blk + 1, w1, WeightPrefetch{w0, ws, lane, q});
+        }
+    } else {
+        if (a.wlds) stage(0);
+        BlockW w;
+        for (int blk = 0; blk < a.n_blocks; ++blk) {
+            if (a.wlds) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
+                __syncthreads();                                  // xin complete, every wave's share has landed
+                load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
+                // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
+                if (blk + 1 < a.n_blocks) stage(blk + 1);
+            } else {  // very long patches: no LDS left for the weight slots, every wave reads the block from L2
+                __syncthreads();
+                load_block_lds(w, Wb + (size_t)blk * kBlockFloats, lane, q);
+            }
+            one_block(blk, w, NoPrefetch());
+        }
     }
     __syncthreads();
     save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
@@ -298,62 +409,80 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     }
     __syncthreads();
 
-    // ---- Dense layers on the flattened trunk: D[o][g] = sum_k WhT[o][k] * flat[g][k], k = t*32 + c ----
-    // A (weights) pre-packed per M-tile as [k/16][lane][4]: one 16-byte load feeds four MFMA steps.
-    // Waves beyond the number of M-tiles split the k range (partial sums are added in the epilogue).
-    float *pre = xout;  // scratch [nks][kMaxG][kPS]: the other activation buffer is free now
-    const int steps4 = a.D / 16;
-    const int nks = max(1, nw / a.n_mt);
-    {
-        const int mt = wave % a.n_mt, ks = wave / a.n_mt;
-        if (ks < nks && !a.skip_heads) {
-            const int s_lo = (int)((long)steps4 * ks / nks), s_hi = (int)((long)steps4 * (ks + 1) / nks);
-            const f32x4 *wa = reinterpret_cast<const f32x4 *>(WhA) + (size_t)mt * steps4 * 64 + lane;
-            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-            const bool live = j < g_here;
-            const float *xg = xin + (size_t)(live ? j : 0) * T * SX + q;
-            // The weights stream from L2 (one 16-byte load per lane and step): kHB loads are issued before the
-            // products of the previous group run, so a full group is always in flight (this loop was latency-bound).
-            constexpr int kHB = 16;
-            f32x4 wcur[kHB], wnxt[kHB];
+    // ---- Dense layers on the flattened trunk: pre[g][o] = sum_k flat[g][k] * Wh[k][o], k = t*32 + c, o < NH (51 or 69) ----
+    // On the VALU, not on the matrix cores: with 4 patches per workgroup a 16-column MFMA tile is 75 % padding, and exact-f32
+    // MFMA has the same peak as v_fma_f32 -- the padded product cost 4x the arithmetic (and ran at 17 us per launch,
+    // waiting for its weights).  Here a lane owns one output (two when NH > 64), a wave owns a range of frames; per frame
+    // it streams 32 rows of Wh (256 contiguous bytes per row and wave) and multiplies them with the four patches'
+    // activations, which are wave-uniform LDS reads.  The waves' partial sums meet in LDS.
+    const int OPL = (a.NH + 63) >> 6;           // outputs per lane
+    const int ld = OPL * 64;                    // row length of the packed weights Wh[k][ld]
+    // The frames are cut into kDenseParts fixed ranges (a function of T alone) and the ranges are summed in a fixed order, so
+    // a patch gets the same bits whatever the batch size, the patches per workgroup or the number of waves.
+    constexpr int kDenseParts = 8;
+    float *part = xout;                         // [kDenseParts][4][ld] partial sums, then pre[kMaxG][kPS] behind them
+    float *pre = xout + (size_t)kDenseParts * 4 * ld;
+    const int rpp = (T + kDenseParts - 1) / kDenseParts;
+    auto dense_on_trunk = [&](auto opl_c) {
+        constexpr int kOPL = decltype(opl_c)::value;
+        for (int g0 = 0; g0 < g_here; g0 += 4) {
+            const float *xg[4];
 #pragma unroll
-            for (int e = 0; e < kHB; ++e) wcur[e] = wa[(size_t)min(s_lo + e, s_hi - 1) * 64];
-            for (int s0 = s_lo; s0 < s_hi; s0 += kHB) {
+            for (int g = 0; g < 4; ++g) xg[g] = xin + (size_t)min(g0 + g, g_here - 1) * T * SX;
+            for (int pt = wave; pt < kDenseParts; pt += nw) {
+                const int t_lo = min(T, pt * rpp), t_hi = min(T, t_lo + rpp);
+                float acc[4][kOPL];
 #pragma unroll
-                for (int e = 0; e < kHB; ++e) wnxt[e] = wa[(size_t)min(s0 + kHB + e, s_hi - 1) * 64];
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < kHB; ++e) {
-                    const int s4 = s0 + e;
-                    if (s4 < s_hi) {
-                        // k = 16*s4 + 4*e + q  ->  t = s4 / 2, c = 16*(s4 & 1) + 4*e + q
-                        const float *xr = xg + (size_t)(s4 >> 1) * SX + 16 * (s4 & 1);
-                        float b0 = xr[0], b1 = xr[4], b2 = xr[8], b3 = xr[12];
-                        if (!live) b0 = b1 = b2 = b3 = 0.f;
-                        accA = mfma4(wcur[e][0], b0, accA);
-                        accB = mfma4(wcur[e][1], b1, accB);
-                        accA = mfma4(wcur[e][2], b2, accA);
-                        accB = mfma4(wcur[e][3], b3, accB);
+                    for (int p = 0; p < kOPL; ++p) acc[g][p] = 0.f;
+                for (int t = t_lo; t < t_hi; ++t) {
+                    const float *wrow = WhA + (size_t)t * C * ld + lane;
+#pragma unroll 1
+                    for (int c8 = 0; c8 < 4; ++c8) {
+                        float wv[8][kOPL];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+#pragma unroll
+                            for (int p = 0; p < kOPL; ++p) wv[c][p] = wrow[(size_t)(8 * c8 + c) * ld + 64 * p];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 xa = *reinterpret_cast<const f32x4 *>(xg[g] + (size_t)t * SX + 8 * c8);
+                            const f32x4 xb = *reinterpret_cast<const f32x4 *>(xg[g] + (size_t)t * SX + 8 * c8 + 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                                for (int p = 0; p < kOPL; ++p) {
+                                    acc[g][p] = fmaf(xa[c], wv[c][p], acc[g][p]);
+                                    acc[g][p] = fmaf(xb[c], wv[4 + c][p], acc[g][p]);
+                                }
+                        }
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < kHB; ++e) wcur[e] = wnxt[e];
-            }
-            accA += accB;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pre[(ks * kMaxG + j) * kPS + 16 * mt + 4 * q + r] = accA[r];
+                    for (int p = 0; p < kOPL; ++p) part[((size_t)pt * 4 + g) * ld + 64 * p + lane] = acc[g][p];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4 * ld; i += blockDim.x) {  // ordered sum over the parts: deterministic
+                const int g = i / ld, o = i - g * ld;
+                if (g0 + g < g_here && o < kPS) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < kDenseParts; ++pt) v += part[((size_t)pt * 4 + g) * ld + o];
+                    pre[(g0 + g) * kPS + o] = v;
+                }
+            }
+            __syncthreads();
         }
-    }
-    __syncthreads();
-    if (nks > 1) {
-        for (int i = threadIdx.x; i < kMaxG * kPS; i += blockDim.x) {
-            float v = pre[i];
-            for (int k2 = 1; k2 < nks; ++k2) v += pre[k2 * kMaxG * kPS + i];
-            pre[i] = v;
-        }
-        __syncthreads();
+    };
+    if (!a.skip_heads) {
+        if (OPL == 1) dense_on_trunk(std::integral_constant<int, 1>{});
+        else dense_on_trunk(std::integral_constant<int, 2>{});
     }
     // ---- BN / relu / output Dense / activations: one thread per (patch, head), one per patch for 3C ----
-    const float *bh = WhA + (size_t)a.n_mt * steps4 * 64 * 4;  // NH biases follow the packed weights
+    const float *bh = WhA + (size_t)a.D * ld;  // NH biases follow the packed weights
     if constexpr (TRAIN) {  // training: the batch-statistics heads run in smh_train.hip on `pre`
         for (int i = threadIdx.x; i < g_here * kPS; i += blockDim.x) {
             const int p = i / kPS, o = i - p * kPS;
@@ -445,7 +574,7 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
             for (int mt = 0; mt < 2; ++mt)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int q = lane >> 4, i = lane & 15;
-                    const int tap = s / 8, c = (4 * s) % 32 + q;
+                    const int tap = s / 8, c = 8 * q + s % 8;  // run_block: lane group q feeds channel 8 q + s8 at step s8
                     const int n = s * 2 + mt;
                     wb[(n / 4) * 256 + 4 * lane + n % 4] = k1[((size_t)tap * C + c) * C + 16 * mt + i];
                 }
@@ -482,16 +611,11 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
         php += cnt;
         p += cnt;
     }
-    // A-operand packing: WhA[mt][s4][lane][e] = Wh[k = 16*s4 + 4*e + q][o = 16*mt + i]   (0 for o >= NH)
-    const int steps4 = D / 16;
-    for (int mt = 0; mt < m->n_mt; ++mt)
-        for (int s4 = 0; s4 < steps4; ++s4)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 4; ++e) {
-                    const int q = lane >> 4, i = lane & 15, k = 16 * s4 + 4 * e + q, o = 16 * mt + i;
-                    WhA[(((size_t)mt * steps4 + s4) * 64 + lane) * 4 + e] = o < NH ? Wh[(size_t)k * NH + o] : 0.f;
-                }
-    std::memcpy(&WhA[(size_t)m->n_mt * steps4 * 64 * 4], bhv.data(), bhv.size() * sizeof(float));
+    // Wh[k][ld], ld = 64 * ceil(NH / 64): row k = the NH outputs of input k (then zeros), read one row per wave and k
+    const int ld = 64 * ((NH + 63) / 64);
+    for (int k = 0; k < D; ++k)
+        for (int o = 0; o < NH; ++o) WhA[(size_t)k * ld + o] = Wh[(size_t)k * NH + o];
+    std::memcpy(&WhA[(size_t)D * ld], bhv.data(), bhv.size() * sizeof(float));
 }
 
 }  // namespace
@@ -547,11 +671,12 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     }
     a.G = G;
     int GRP = ((G * T + 15) / 16) * 16;
-    if (GRP * SX < 2 * kMaxG * kPS) GRP = (2 * kMaxG * kPS + SX - 1) / SX;  // the head scratch lives in one buffer
+    const int head_scratch = 8 * 4 * 128 + kMaxG * kPS;  // Dense partial sums (8 parts x 4 patches x <= 128) + pre[kMaxG][kPS]
+    if (GRP * SX < head_scratch) GRP = (head_scratch + SX - 1) / SX;  // the head scratch lives in one buffer
     if (GRP * SX < m->FQ * 2 * 64) GRP = (m->FQ * 2 * 64 + SX - 1) / SX;  // layer-0 A operands are staged there
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
-    const size_t lds_x = sizeof(float) * 2 * (size_t)GRP * SX, lds_w = sizeof(float) * 2 * (size_t)kBlockFloats;
+    const size_t lds_x = sizeof(float) * 2 * (size_t)(GRP + 1) * SX, lds_w = sizeof(float) * 2 * (size_t)kBlockFloats;  // + the zero rows
     a.wlds = lds_x + lds_w <= 156 * 1024 ? 1 : 0;  // activations (x2) + two weight slots, when they fit
     *plds = lds_x + (a.wlds ? lds_w : 0);
 }
@@ -574,18 +699,27 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
         if ((units + w - 1) / w < (units + nwaves - 1) / nwaves) nwaves = w;
     if (const char *ev = getenv("SMH_TCN_WAVES")) nwaves = std::max(4, std::min(12, atoi(ev)));  // tuning only
     const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
+    // 8 waves (two per SIMD, 256 VGPRs each): two weight register sets, the next block's weights are read behind this
+    // block's products.  More waves (170 VGPRs): one set, read at the top of the block.
+    bool prefetch = nwaves <= 8 && a.wlds;
+    if (const char *ev = getenv("SMH_TCN_PREFETCH")) prefetch = prefetch && atoi(ev) != 0;  // tuning only
+    TrainIO io{nullptr, nullptr, nullptr};
+    if (tio) io = *tio;
+#define SMH_LAUNCH_FWD(TR, PF)                                                                                          \
+    do {                                                                                                                \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<TR, PF>,                                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL((b3mtl_forward_kernel<TR, PF>), grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA,   \
+                           m->d_hp, d_trunk, d_out, io);                                                               \
+    } while (0)
     if (tio) {
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(b3mtl_forward_kernel<true>, grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA, m->d_hp,
-                           d_trunk, d_out, *tio);
+        if (prefetch) SMH_LAUNCH_FWD(true, true);
+        else SMH_LAUNCH_FWD(true, false);
     } else {
-        TrainIO none{nullptr, nullptr, nullptr};
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(b3mtl_forward_kernel<false>, grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA, m->d_hp,
-                           d_trunk, d_out, none);
+        if (prefetch) SMH_LAUNCH_FWD(false, true);
+        else SMH_LAUNCH_FWD(false, false);
     }
+#undef SMH_LAUNCH_FWD
     return smh::launch_status("b3mtl_forward_kernel");
 }
 
@@ -626,7 +760,7 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     SMH_REQUIRE(n < (1u << 24), "model too large for the float-encoded gather map");
     m->nW0 = (size_t)m->FQ * 2 * 64 + 32;
     m->nWb = (size_t)m->n_blocks * kBlockFloats;
-    m->nWhA = (size_t)m->n_mt * (m->D / 16) * 64 * 4 + (size_t)m->n_mt * 16;
+    m->nWhA = (size_t)m->D * 64 * ((m->NH + 63) / 64) + (size_t)m->n_mt * 16;
     m->nhp = 0;
     for (int i = 0; i < m->n_heads; ++i) m->nhp += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
     // gather map = the host packing applied to 1, 2, 3, ... (0 marks padding)

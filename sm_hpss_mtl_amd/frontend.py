@@ -265,3 +265,54 @@ class Frontend:
         if taps:
             res.update(S=S, harm=harm, perc=perc)
         return res
+
+    # ---- ragged batches ----
+    def run_ragged(self, clips, W=None, shift=None):
+        """Clips of DIFFERENT lengths in one call (`smh_frontend_ragged_f32`).  clips: list of 1-D float32 arrays / tensors.
+        Returns dict(fv=[(2*rows, T_b) tensors], patches=[(nP_b, W, 2*rows) tensors] (views of one buffer each),
+        n_patches=[...], T=[...]).  Every clip gets bit for bit what `run` gives it alone or in an equal-length batch:
+        the clips are laid out at 16-byte aligned offsets, so each takes the same kernels as there."""
+        B = len(clips)
+        if B == 0:
+            return {"fv": [], "patches": [], "n_patches": [], "T": []}
+        dev = torch.device("cuda", torch.cuda.current_device())
+        lens = [int(c.shape[0]) for c in clips]
+        offs, o = [], 0
+        for n in lens:
+            offs.append(o)
+            o += (n + 3) // 4 * 4  # next clip starts on a 16-byte boundary
+        audio = torch.zeros(max(o, 1), dtype=torch.float32, device=dev)
+        for c, n, of in zip(clips, lens, offs):
+            t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
+            if t.dim() != 1:
+                raise ValueError("run_ragged: every clip must be 1-D")
+            audio[of:of + n] = t.to(device=dev, dtype=torch.float32)
+        h_off = (C.c_longlong * B)(*offs)
+        h_len = (C.c_int * B)(*lens)
+        fv_off, p_off = (C.c_longlong * (B + 1))(), (C.c_longlong * (B + 1))()
+        hT, hnP = (C.c_int * B)(), (C.c_int * B)()
+        work = C.c_size_t()
+        _lib.check(self.lib.smh_frontend_ragged_sizes(self._h, h_off, h_len, B, W or 0, shift or 0, fv_off, p_off, hT, hnP,
+                                                      C.byref(work)), "smh_frontend_ragged_sizes")
+        F = 2 * self.rows
+        fv = torch.empty(max(int(fv_off[B]), 1), dtype=torch.float32, device=dev)
+        patches = torch.empty((max(int(p_off[B]), 1), W or 1, F), dtype=torch.float32, device=dev) if W else None
+        if self._work is None or self._work.numel() < work.value or self._work.device != dev:
+            self._work = torch.empty(max(work.value, 1), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.smh_frontend_ragged_f32(self._h, _ptr(audio), h_off, h_len, B, W or 0, shift or 0, _ptr(fv),
+                                                    _ptr(patches) if (W and int(p_off[B]) > 0) else None, _ptr(self._work),
+                                                    self._work.numel(), _stream()), "smh_frontend_ragged_f32")
+        res = {"fv": [fv[int(fv_off[b]):int(fv_off[b + 1])].view(F, int(hT[b])) for b in range(B)],
+               "T": [int(hT[b]) for b in range(B)], "n_patches": [int(hnP[b]) for b in range(B)]}
+        if W:
+            res["patches"] = [patches[int(p_off[b]):int(p_off[b + 1])] for b in range(B)]
+        return res
+
+    def patches_from_featuregram(self, fv, W, shift):
+        """get_feature_patches for the TCN models on the device: featuregram (2*rows, T) [rows 0..F/2-1 harmonic] ->
+        standardised time-major patches (nP, W, 2*rows) (tile-if-short, StandardScaler per half, extract_patches, transpose)."""
+        fv = _f32c(fv, "fv")
+        if fv.dim() != 2:
+            raise ValueError("FV should be of the shape (nFeatures, nFrames)")
+        x = self.standardize_rows(fv)  # per row over the frames: the per-half scaler is row-wise, so halves need no split
+        return self.extract_patches(x[None], W, shift, time_major=True)

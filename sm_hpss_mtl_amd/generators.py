@@ -1,0 +1,274 @@
+"""Counterparts of the reference's two data generators, the callers of the hot path:
+
+  generator(PARAMS, folder, file_list, batchSize)                       Proposed_Work_Results.py:49-270
+  test_file_wise_generator(PARAMS, file_name_sp, file_name_mu, target_dB)  Proposed_Work_Results.py:459-496
+
+Same arguments, same PARAMS keys, same batch composition and label rules, same use of numpy's global random state
+(`np.random.shuffle` / `np.random.choice`: seed it the way the reference's driver would).  What differs is WHERE the work
+happens: the reference computes one file at a time on the CPU and grows its buffers with `np.append`; here the files a
+batch needs are decided first -- the number of patches a file yields is an integer contract of its length
+(`smh_num_frames` / `smh_tiled_frames` / `smh_num_patches`), and silence removal keeps the length -- and then go through
+the HIP front end together as ONE ragged device batch (`Frontend.run_ragged`); patches stay on the device as float32
+tensors in the network's (N, W, 2F) layout.  Per-file results do not depend on what else is in the batch, so the yielded
+batches are the ones the sequential loop would yield.
+
+`featuregram_fn` / `patches_fn` are injection points for tests (and for a CPU oracle): per-file callables with the
+signatures of `preproc.get_featuregram` / `preproc.get_feature_patches`.  When they are given, files are processed one
+by one through them, exactly like the reference's loop.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import batching
+
+HARDCODED_TEST_SHIFT = 68  # Proposed_Work_Results.py:474 passes 68 as patch_shift whatever PARAMS['W_shift'] says
+
+
+def to_categorical(labels, num_classes):
+    """tensorflow.keras.utils.to_categorical for a 1-D integer label list (float32 one-hot)."""
+    labels = np.asarray(labels, dtype=np.int64).reshape(-1)
+    out = np.zeros((labels.size, int(num_classes)), dtype=np.float32)
+    out[np.arange(labels.size), labels] = 1.0
+    return out
+
+
+class _ClassBuffer:
+    """One class's buffer of patches: grows file by file until it holds a batch, hands out the first batchSize rows."""
+
+    def __init__(self):
+        self.chunks, self.balance, self.meta = [], 0, []
+
+    def add(self, patches, meta=None):
+        n = int(patches.shape[0])
+        if n == 0:
+            return
+        self.chunks.append(patches)
+        self.meta.extend([meta] * n)
+        self.balance += n
+
+    def take(self, n):
+        import torch
+        if isinstance(self.chunks[0], np.ndarray):
+            data = np.concatenate(self.chunks, axis=0)
+        else:
+            data = torch.cat(self.chunks, dim=0)
+        head, rest = data[:n], data[n:]
+        meta, self.meta = self.meta[:n], self.meta[n:]
+        self.chunks = [rest] if rest.shape[0] else []
+        self.balance -= n
+        return head, meta
+
+
+def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
+    """specs: list of (classname, sp_path, mu_path, target_dB).  Loads / conditions / mixes the signals (the 'next' row in
+    front of the path: lib.preprocessing.load_and_preprocess_signal, mix_signals), then ONE ragged pass of the front end.
+    Returns a list of (nP_i, W, 2F) float32 device tensors."""
+    import torch
+    from . import frontend as _fe
+    from .lib import preprocessing as pp
+    if 'Lemaire_et_al' not in PARAMS['Model']:
+        raise ValueError("the device generator yields the TCN layout (N, W, F): Model must be a Lemaire_et_al variant")
+    clips = []
+    for classname, sp, mu, db in specs:
+        cache = pp.feature_cache_path(PARAMS['feature_opDir'], classname, sp, mu, db)
+        if os.path.exists(cache):
+            clips.append(("fv", np.load(cache, allow_pickle=False)))
+            continue
+        if classname == 'speech_music':
+            x_sp, _ = pp.load_and_preprocess_signal(sp, PARAMS['Tw'], PARAMS['Ts'])
+            x_mu, _ = pp.load_and_preprocess_signal(mu, PARAMS['Tw'], PARAMS['Ts'])
+            x = pp.mix_signals(x_sp, x_mu, db)
+        elif classname == 'speech':
+            x, _ = pp.load_and_preprocess_signal(sp, PARAMS['Tw'], PARAMS['Ts'])
+        else:
+            x, _ = pp.load_and_preprocess_signal(mu, PARAMS['Tw'], PARAMS['Ts'])
+        clips.append(("audio", np.ascontiguousarray(x, dtype=np.float32), cache))
+    cfg = _fe.FrontendConfig.from_params(PARAMS, n_fft, n_mels, featName)
+    fe = pp._frontend_for(cfg)
+    out = [None] * len(clips)
+    audio_idx = [i for i, c in enumerate(clips) if c[0] == "audio"]
+    if audio_idx:
+        res = fe.run_ragged([clips[i][1] for i in audio_idx], W=W, shift=shift)
+        for k, i in enumerate(audio_idx):
+            out[i] = res["patches"][k]
+            if PARAMS.get('save_features', True):  # get_featuregram(save_feat=True): the reference's .npy cache
+                os.makedirs(os.path.dirname(clips[i][2]), exist_ok=True)
+                np.save(clips[i][2], res["fv"][k].cpu().numpy())
+    for i, c in enumerate(clips):
+        if c[0] == "fv":  # cached featuregram: standardise + patches only
+            fv = torch.from_numpy(np.ascontiguousarray(c[1], dtype=np.float32)).cuda()
+            out[i] = fe.patches_from_featuregram(fv, W, shift)
+    return out
+
+
+def _n_patches_of_file(PARAMS, path, n_fft, W, shift, lengths_cache):
+    """Patches a file will yield, from its length alone (bit-exact integer contracts; silence removal keeps the length)."""
+    from . import _lib
+    from .lib import preprocessing as pp
+    n = lengths_cache.get(path)
+    if n is None:
+        n = lengths_cache[path] = pp.audio_num_samples(path)
+    lib = _lib.load()
+    fs = 16000
+    hop = int(PARAMS['Ts'] * fs / 1000)
+    if n / fs < 0.1:  # load_and_preprocess_signal doubles clips shorter than 0.1 s (preprocessing.py:343-346)
+        while n / fs < 0.1:
+            n *= 2
+    T = lib.smh_num_frames(int(n), int(n_fft), hop)
+    if T < 1:
+        return 0
+    return lib.smh_num_patches(lib.smh_tiled_frames(T, int(W)), int(W), int(shift))
+
+
+def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches_fn=None):
+    """Infinite class-balanced batch generator: yields (batchData, labels).
+
+    batchData: [batchSize music | batchSize speech | batchSize speech+music] patches, (3*batchSize, W, 2F) for the TCN
+    models ((.., 2F, W, 1) for the Conv2D ones when the per-file callables are injected); labels: {'R', 'S', 'M', '3C'} for
+    the MTL models (the S = M = 0 rule for mixtures included, Proposed_Work_Results.py:249-260), else the one-hot matrix."""
+    batch_count = 0
+    np.random.shuffle(file_list['speech'])
+    np.random.shuffle(file_list['music'])
+    file_list_sp_temp = file_list['speech'].copy()
+    file_list_mu_temp = file_list['music'].copy()
+    three = len(PARAMS['classes']) == 3
+    if three:
+        np.random.shuffle(file_list['speech+music'])
+        file_list_spmu_temp = file_list['speech+music'].copy()
+    for sub in ('speech', 'music') + (('speech_music',) if three else ()):
+        os.makedirs(PARAMS['feature_opDir'] + '/' + sub + '/', exist_ok=True)
+    n_fft = PARAMS['n_fft'][PARAMS['Model']]
+    n_mels = PARAMS['n_mels'][PARAMS['Model']]
+    featName = PARAMS['featName'][PARAMS['Model']]
+    W, W_shift = PARAMS['W'], PARAMS['W_shift']
+    if PARAMS.get('frame_level_scaling') or PARAMS.get('skewness_vector'):
+        raise ValueError("frame_level_scaling / skewness_vector are off in every reference configuration of this path "
+                         "(Proposed_Work_Results.py:802-804) and are not wired into the generator")
+    per_file = featuregram_fn is not None or patches_fn is not None
+    if per_file:
+        from .lib import preprocessing as pp
+        featuregram_fn = featuregram_fn or pp.get_featuregram
+        patches_fn = patches_fn or pp.get_feature_patches
+    lengths = {}
+    buf = {'speech': _ClassBuffer(), 'music': _ClassBuffer(), 'speech_music': _ClassBuffer()}
+    rng = np.random  # the reference draws from numpy's global state
+
+    def one_file(spec):
+        classname, sp, mu, db = spec
+        fv = featuregram_fn(PARAMS, classname, PARAMS['feature_opDir'], sp, mu, db, n_fft, n_mels, featName)
+        return patches_fn(PARAMS, fv, W, W_shift, featName)
+
+    def fill(classname, next_spec):
+        """Pop files until the class buffer holds a batch (the reference's `while balance < batchSize` loops)."""
+        b = buf[classname]
+        if per_file:
+            while b.balance < batchSize:
+                spec = next_spec()
+                if spec is None:
+                    continue
+                b.add(one_file(spec), spec[3])
+            return
+        specs, predicted = [], b.balance
+        while predicted < batchSize:
+            spec = next_spec()
+            if spec is None:
+                continue
+            # a mixture has the length of its speech file: the music is looped / cut to it (preprocessing.py:303-310)
+            n = _n_patches_of_file(PARAMS, spec[2] if classname == 'music' else spec[1], n_fft, W, W_shift, lengths)
+            specs.append(spec)
+            predicted += n
+        for spec, patches in zip(specs, _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, W_shift)):
+            b.add(patches, spec[3])
+        if b.balance < batchSize:  # a cached featuregram was shorter than its file predicted: top up file by file
+            fill(classname, next_spec)
+
+    def next_speech():
+        nonlocal file_list_sp_temp
+        if not file_list_sp_temp:
+            file_list_sp_temp = file_list['speech'].copy()
+        path = folder + '/speech/' + file_list_sp_temp.pop()
+        return ('speech', path, '', None) if os.path.exists(path) else None
+
+    def next_music():
+        nonlocal file_list_mu_temp
+        if not file_list_mu_temp:
+            file_list_mu_temp = file_list['music'].copy()
+        path = folder + '/music/' + file_list_mu_temp.pop()
+        return ('music', '', path, None) if os.path.exists(path) else None
+
+    def next_mix():
+        nonlocal file_list_spmu_temp
+        if not file_list_spmu_temp:
+            file_list_spmu_temp = file_list['speech+music'].copy()
+        np.random.shuffle(file_list_spmu_temp)  # the reference reshuffles before every pop (:181)
+        info = file_list_spmu_temp.pop()
+        sp, mu = folder + '/speech/' + info['speech'], folder + '/music/' + info['music']
+        return ('speech_music', sp, mu, info['SMR']) if (os.path.exists(sp) and os.path.exists(mu)) else None
+
+    while 1:
+        fill('speech', next_speech)
+        fill('music', next_music)
+        data_mu, _ = buf['music'].take(batchSize)
+        data_sp, _ = buf['speech'].take(batchSize)
+        parts = [data_mu, data_sp]
+        smr = None
+        if three:
+            fill('speech_music', next_mix)
+            data_mix, smr = buf['speech_music'].take(batchSize)
+            parts.append(data_mix)
+        if isinstance(parts[0], np.ndarray):
+            batchData = np.concatenate(parts, axis=0)
+            if 'Lemaire_et_al' in PARAMS['Model']:
+                batchData = np.transpose(batchData, axes=(0, 2, 1))  # per-file callables return (nP, F, W)
+        else:
+            import torch
+            batchData = torch.cat(parts, dim=0)  # device patches are already (N, W, F)
+        if PARAMS['data_augmentation_with_noise']:
+            batchData = batching.noise_augmentation(batchData, rng)
+        if three:
+            lab = batching.make_labels_3class(batchSize, np.asarray(smr, dtype=np.float64))
+        else:  # two classes: only music / speech rows
+            lab = batching.make_labels_3class(batchSize, np.zeros(batchSize))
+            lab = {k: v[:2 * batchSize] for k, v in lab.items()}
+            lab['3C'] = to_categorical([0] * batchSize + [1] * batchSize, 2)
+        batch_count += 1
+        if 'MTL' in PARAMS['Model']:
+            yield batchData, lab
+        else:
+            yield batchData, lab['3C']
+
+
+def test_file_wise_generator(PARAMS, file_name_sp, file_name_mu, target_dB, featuregram_fn=None, patches_fn=None):
+    """All patches of ONE test file + their one-hot labels (Proposed_Work_Results.py:459-496).  The patch shift is the
+    reference's hard-coded 68, not PARAMS['W_shift'].  Device path: float32 tensor (nP, W, 2F); with the per-file callables
+    injected: what they return, transposed to (nP, W, F) for the TCN models."""
+    n_fft = PARAMS['n_fft'][PARAMS['Model']]
+    n_mels = PARAMS['n_mels'][PARAMS['Model']]
+    featName = PARAMS['featName'][PARAMS['Model']]
+    if PARAMS.get('frame_level_scaling') or PARAMS.get('skewness_vector'):
+        raise ValueError("frame_level_scaling / skewness_vector are not wired into this path")
+    if file_name_mu == '':
+        spec, label = ('speech', file_name_sp, '', None), 1
+    elif file_name_sp == '':
+        spec, label = ('music', '', file_name_mu, None), 0
+    else:
+        spec, label = ('speech_music', file_name_sp, file_name_mu, target_dB), 2
+    if featuregram_fn is not None or patches_fn is not None:
+        from .lib import preprocessing as pp
+        fv = (featuregram_fn or pp.get_featuregram)(PARAMS, spec[0], PARAMS['feature_opDir'], spec[1], spec[2], spec[3], n_fft,
+                                                     n_mels, featName, save_feat=False)
+        batchData = (patches_fn or pp.get_feature_patches)(PARAMS, fv, PARAMS['W'], HARDCODED_TEST_SHIFT, featName)
+        if 'Lemaire_et_al' in PARAMS['Model']:
+            batchData = np.transpose(batchData, axes=(0, 2, 1))
+    else:
+        saved = PARAMS.get('save_features', True)
+        PARAMS['save_features'] = False  # save_feat=False at :465-469
+        try:
+            batchData = _device_patches_for(PARAMS, [spec], featName, n_fft, n_mels, PARAMS['W'], HARDCODED_TEST_SHIFT)[0]
+        finally:
+            PARAMS['save_features'] = saved
+    numLab = int(batchData.shape[0])
+    return batchData, to_categorical([label] * numLab, num_classes=len(PARAMS['classes']))

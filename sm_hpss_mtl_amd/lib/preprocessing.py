@@ -40,25 +40,11 @@ def normalize_signal(Xin):
 
 
 def mix_signals(Xin_sp, Xin_mu, target_dB):
-    """preprocessing.py:297-325 (music looped to the speech length, scaled to the target SMR)."""
-    sig_sp_len = len(Xin_sp)
-    Xin_mu_temp = Xin_mu.copy()
-    while len(Xin_mu_temp) < sig_sp_len:
-        Xin_mu_temp = np.append(Xin_mu_temp, Xin_mu)
-    common_len = min(sig_sp_len, len(Xin_mu_temp))
-    Xin_sp = Xin_sp[:common_len]
-    Xin_mu = Xin_mu_temp[:common_len]
-    sig_sp_energy = np.sum(np.power(Xin_sp, 2)) / len(Xin_sp)
-    sig_mu_energy = np.sum(np.power(Xin_mu, 2)) / len(Xin_mu)
-    req_sig_mu_energy = sig_sp_energy / np.power(10, (target_dB / 10))
-    sig_mu_mult_fact = np.sqrt(req_sig_mu_energy / sig_mu_energy)
-    sig_sp_mult_fact = 1
-    mult_fact_sum = sig_mu_mult_fact + sig_sp_mult_fact
-    sig_mu_mult_fact /= mult_fact_sum
-    sig_sp_mult_fact /= mult_fact_sum
-    dt = Xin_sp.dtype
-    Xin_mix = (dt.type(sig_sp_mult_fact) * Xin_sp + dt.type(sig_mu_mult_fact) * Xin_mu).astype(dt)
-    return normalize_signal(Xin_mix)
+    """preprocessing.py:297-325 for one pair of signals: a batch of one through `smh_mix_signals_f32` (music looped / cut to
+    the speech length, scaled to the target speech-to-music ratio, factors normalised to sum 1, then `normalize_signal`)."""
+    sp = torch.from_numpy(np.ascontiguousarray(Xin_sp, dtype=np.float32)).cuda()[None]
+    mu = torch.from_numpy(np.ascontiguousarray(Xin_mu, dtype=np.float32)).cuda()[None]
+    return mix_signals_batch(sp, mu, [float(target_dB)])[0].cpu().numpy()
 
 
 def removeSilence(Xin, fs, Tw, Ts, alpha=0.025, beta=0.075):
@@ -113,6 +99,39 @@ def _read_audio(fName, sr=16000):
     return x, sr
 
 
+def audio_num_samples(fName, sr=16000):
+    """Samples `_read_audio` will return for this file (after resampling to sr), from the header alone where possible."""
+    if fName.endswith(".npy"):
+        return int(np.load(fName, mmap_mode="r").shape[0])
+    import wave
+    try:
+        with wave.open(fName, "rb") as w:
+            n, fs = w.getnframes(), w.getframerate()
+    except (wave.Error, EOFError):  # float / extensible WAV: let scipy parse it
+        x, _ = _read_audio(fName, sr)
+        return int(len(x))
+    if fs == sr:
+        return int(n)
+    from math import gcd
+    g = gcd(int(fs), int(sr))
+    up, down = sr // g, fs // g
+    return int(-(-n * up // down))  # scipy.signal.resample_poly: ceil(n * up / down)
+
+
+def feature_cache_path(feature_opDir, classname, fName_path_sp, fName_path_mu, target_dB):
+    """<feature_opDir>/<classname>/<name>.npy as get_featuregram names it (preprocessing.py:357-363)."""
+    if (fName_path_sp != '') and (fName_path_mu != ''):
+        fName = (fName_path_sp.split('/')[-1].split('.')[0] + '_' + fName_path_mu.split('/')[-1].split('.')[0]
+                 + '_' + str(target_dB) + 'dB')
+    elif fName_path_sp != '':
+        fName = fName_path_sp.split('/')[-1].split('.')[0]
+    elif fName_path_mu != '':
+        fName = fName_path_mu.split('/')[-1].split('.')[0]
+    else:
+        raise ValueError("get_featuregram: both file paths are empty")
+    return feature_opDir + '/' + classname + '/' + fName + '.npy'
+
+
 def preprocess_signal_batch(Xin, fs, Tw, Ts):
     """preprocessing.py:332-349 for a float32 CUDA tensor (B, N) of equal-length clips, device resident.
     Returns (Xin_silrem (B, N), n_keep (B,)): like the reference the output keeps the input length, retained
@@ -150,16 +169,7 @@ def featuregram_from_signal(PARAMS, Xin, n_fft, n_mels, featName, fs=16000):
 def get_featuregram(PARAMS, classname, feature_opDir, fName_path_sp, fName_path_mu, target_dB, n_fft, n_mels,
                     featName, save_feat=True):
     """preprocessing.py:355-457: same naming, same .npy cache layout <feature_opDir>/<class>/<name>.npy."""
-    if (fName_path_sp != '') and (fName_path_mu != ''):
-        fName = (fName_path_sp.split('/')[-1].split('.')[0] + '_' + fName_path_mu.split('/')[-1].split('.')[0]
-                 + '_' + str(target_dB) + 'dB')
-    elif fName_path_sp != '':
-        fName = fName_path_sp.split('/')[-1].split('.')[0]
-    elif fName_path_mu != '':
-        fName = fName_path_mu.split('/')[-1].split('.')[0]
-    else:
-        raise ValueError("get_featuregram: both file paths are empty")
-    cache = feature_opDir + '/' + classname + '/' + fName + '.npy'
+    cache = feature_cache_path(feature_opDir, classname, fName_path_sp, fName_path_mu, target_dB)
     if os.path.exists(cache):
         return np.load(cache, allow_pickle=False)
     if featName not in _fe.FEATS:

@@ -26,10 +26,11 @@ def _p(t):
 
 class HotPath:
     def __init__(self, fe, model, batch, n_samples, patch=68, shift=None, fuse_l0=True, two_kernel_features=False,
-                 model_dtype="f32", keep_patches=False, device=None):
+                 model_dtype="f32", keep_patches=False, keep_trunk=False, device=None):
         """fe: Frontend, model: B3MTL.  fuse_l0: the network's first 1x1 convolution runs inside the feature kernel
         (smh_features_l0_f32 + smh_model_forward_x0_f32) instead of patches -> smh_model_forward_f32.
-        keep_patches: also write the standardised time-major patches (a parity tap; never set by bench.py)."""
+        keep_patches / keep_trunk: also write the standardised time-major patches / the TCN output (N, W, 32) -- parity taps
+        that `model.predict` does not return; never set by bench.py."""
         self.fe, self.model, self.lib, self._h = fe, model, fe.lib, fe._h
         self.B, self.n_samples, self.W = int(batch), int(n_samples), int(patch)
         self.shift = int(patch if shift is None else shift)
@@ -56,7 +57,7 @@ class HotPath:
         self.patches = torch.empty((B * self.nP, self.W, F), **f32) if need_patches else None
         self.x0p = torch.empty((B * self.nP, 2, self.W, 32), **f32) if self.fuse_l0 else None
         self.logits = torch.empty((B * self.nP, model.out_dim), **f32)
-        self.trunk = torch.empty((B * self.nP, self.W, 32), **f32) if model_dtype == "f32" else None
+        self.trunk = torch.empty((B * self.nP, self.W, 32), **f32) if (keep_trunk and model_dtype == "f32") else None
         # harmonic median layout: 16-frame blocks when the single feature kernel takes the clip, else time-major
         blocked = self.lib.smh_features_blocked_ok(self._h, T, 1 if self.fuse_l0 else 0) and not two_kernel_features
         self.want_layout = 2 if blocked else 1

@@ -119,7 +119,7 @@ def test_adam_update_and_moving_statistics():
     # ... and the bf16 operand cache follows the optimiser's updates too
     old32 = m.predict(x)
     m.predict(x, dtype="bf16")          # builds the cache from the current weights
-    m.initial_learning_rate = 0.02      # a step large enough to move the outputs visibly
+    m.optimizer.learning_rate = 0.02    # a step large enough to move the outputs visibly
     m.train_on_batch(*_batch(N, H, W, 77), drop=None, drop_heads=None)
     new32, new16 = m.predict(x), m.predict(x, dtype="bf16")
     assert max(np.abs(a - b).max() for a, b in zip(new32, old32)) > 0.2  # a stale cache would reproduce the old outputs
@@ -263,8 +263,9 @@ def test_train_step_at_the_drivers_patch_width():
 def test_fit_reduces_the_loss():
     from sm_hpss_mtl_amd.cnn_models import CnnMTL
     H, W, N = 30, 68, 12
+    from sm_hpss_mtl_amd import optimizers
     m, _ = _model(H, W, seed=11)
-    m.initial_learning_rate = 1e-3
+    m.compile(optimizer=optimizers.Adam(learning_rate=1e-3))
     x, y = _batch(N, H, W, 5)
     yl = [y[k] for k in m.output_names]
     first = m.evaluate(x, yl)
@@ -398,7 +399,9 @@ def test_growing_the_cnn_trainer_keeps_adam_moments_and_step():
         res.append(m.get_weights_dict())
     for k in res[0]:
         delta = np.abs(res[1][k] - w[k]).max()
-        assert np.abs(res[0][k] - res[1][k]).max() <= 2e-3 * delta + 1e-7, k
+        # the two trainers split their reductions differently (partial-sum buffers are sized by the capacity): the gradients
+        # differ in the last bits and Adam's first steps are sign descent, so allow 3 % of the distance travelled
+        assert np.abs(res[0][k] - res[1][k]).max() <= 3e-2 * delta + 1e-6, k  # 1e-6: biases in front of BatchNorm (zero gradient, pure rounding)
     # a trainer that forgot its state restarts the bias correction at step 1: the third update would be ~lr per weight,
     # visibly different
     m, w = _model(30, 68, seed=13)
@@ -407,4 +410,4 @@ def test_growing_the_cnn_trainer_keeps_adam_moments_and_step():
     m._reset_optimizer_state()
     m.train_on_batch(x, y, drop=None, drop_heads=None)
     k = "conv2/kernel"
-    assert np.abs(m.get_weights_dict()[k] - res[1][k]).max() > 0.05 * np.abs(res[1][k] - w[k]).max()
+    assert np.abs(m.get_weights_dict()[k] - res[1][k]).max() > 0.15 * np.abs(res[1][k] - w[k]).max()

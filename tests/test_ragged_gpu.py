@@ -1,0 +1,122 @@
+"""Ragged batches and the device generators on the GPU.
+
+* `Frontend.run_ragged` (`smh_frontend_ragged_f32`): clips of different lengths in one call; every clip must get bit for bit
+  what `Frontend.run` gives it alone and -- for runs of equal lengths -- inside an equal-length batch; against the oracle within
+  the stated tolerances.
+* `generators.generator` / `test_file_wise_generator` on synthetic .npy "files": the device path (files of a batch decided from
+  their lengths, one ragged pass) against the sequential reference loop (`oracle.generators`) driven by the per-file functions.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as ofe, generators as ogen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    return Frontend(FrontendConfig())
+
+
+def test_ragged_equals_per_clip_and_equal_length_batches_bit_for_bit(fe):
+    from sm_hpss_mtl_amd.synth import synth_clips
+    # 1 s clips (the fast kernels), odd lengths (generic STFT), below one patch width (tile-if-short), long files (tiled medians,
+    # streaming feature kernels), a run of three equal-length clips in the middle
+    lens = [16000, 16000, 12345, 30000, 16000, 16000, 16000, 5001, 8000, 160000, 47998]
+    clips = [synth_clips(1, seed=40 + i, n_samples=n)[0] for i, n in enumerate(lens)]
+    res = fe.run_ragged(clips, W=68, shift=34)
+    torch.cuda.synchronize()
+    assert res["T"] == [ofe.num_frames(n, 400, 160) for n in lens]
+    for i, c in enumerate(clips):
+        one = fe.run(torch.from_numpy(c).cuda()[None], W=68, shift=34)
+        assert res["n_patches"][i] == one["n_patches"] == len(ofe.patch_starts(ofe.tile_if_short(np.zeros((1, res["T"][i])), 68).shape[1], 68, 34))
+        assert torch.equal(res["fv"][i], one["fv"][0]), ("fv", i, lens[i])
+        assert torch.equal(res["patches"][i], one["patches"]), ("patches", i, lens[i])
+    batch = fe.run(torch.from_numpy(np.stack(clips[4:7])).cuda(), W=68, shift=34)
+    nP = batch["n_patches"]
+    for k, i in enumerate((4, 5, 6)):
+        assert torch.equal(res["fv"][i], batch["fv"][k]) and torch.equal(res["patches"][i], batch["patches"][k * nP:(k + 1) * nP])
+    for i in (2, 7, 8):  # against the oracle
+        ref = ofe.featuregram(clips[i], "LogMelHarmPercSpec")
+        assert np.max(np.abs(res["fv"][i].cpu().numpy() - ref)) <= 2e-3
+    assert fe.run_ragged([], W=68, shift=34)["fv"] == []
+    with pytest.raises(ValueError):
+        fe.run_ragged([clips[0], clips[0][:300]], W=68, shift=34)  # shorter than n_fft
+
+
+def _params(tmp, sub):
+    m = "Lemaire_et_al_MTL"
+    return {"Model": m, "classes": {0: "music", 1: "speech", 2: "speech_music"}, "feature_opDir": str(tmp / sub), "W": 68, "W_shift": 24,
+            "n_fft": {m: 400}, "n_mels": {m: 120}, "featName": {m: "LogMelHarmPercSpec"}, "frame_level_scaling": False,
+            "skewness_vector": None, "data_augmentation_with_noise": False, "Tw": 25, "Ts": 10,
+            "l_harm": {m: 21}, "l_perc": {m: 11}}
+
+
+def _dataset(tmp):
+    from sm_hpss_mtl_amd.synth import synth_clips
+    folder = tmp / "data"
+    rng = np.random.default_rng(3)
+    names = {"speech": [], "music": []}
+    for cls, n_files in (("speech", 7), ("music", 6)):
+        os.makedirs(folder / cls, exist_ok=True)
+        for i in range(n_files):
+            n = int(rng.integers(9000, 52000))
+            x = synth_clips(1, seed=900 + 31 * i + (0 if cls == "speech" else 500), n_samples=n)[0]
+            np.save(folder / cls / ("%s%02d.npy" % (cls[:2], i)), x)
+            names[cls].append("%s%02d.npy" % (cls[:2], i))
+    mix = [{"speech": names["speech"][i % 7], "music": names["music"][(2 * i) % 6], "SMR": [-5, 0, 5, 10, 15, 20][i % 6]} for i in range(8)]
+    return str(folder), {"speech": names["speech"], "music": names["music"], "speech+music": mix}
+
+
+def test_device_generator_yields_the_batches_of_the_sequential_loop(tmp_path):
+    from sm_hpss_mtl_amd import generators as gen
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    folder, files = _dataset(tmp_path)
+    Pd, Pr = _params(tmp_path, "feat_dev"), _params(tmp_path, "feat_ref")
+    np.random.seed(7)
+    dev = gen.generator(Pd, folder, copy.deepcopy(files), 16)
+    got = [next(dev) for _ in range(4)]
+    np.random.seed(7)
+    ref = ogen.reference_generator(Pr, folder, copy.deepcopy(files), 16, pp.get_featuregram, pp.get_feature_patches)
+    want = [next(ref) for _ in range(4)]
+    for (xb, yb), (xr, yr) in zip(got, want):
+        assert isinstance(xb, torch.Tensor) and xb.is_cuda and xb.dtype == torch.float32 and tuple(xb.shape) == (48, 68, 240) == xr.shape
+        # the fused ragged pass and the per-file wrapper functions standardise with the same arithmetic in different kernels
+        assert np.max(np.abs(xb.cpu().numpy() - xr)) <= 2e-4
+        for k in ("R", "S", "M", "3C"):
+            np.testing.assert_array_equal(np.asarray(yb[k], np.float64), np.asarray(yr[k], np.float64))
+    # both wrote the reference's .npy feature cache; the cached featuregrams agree to the last bit (same kernels)
+    for cls in ("speech", "music", "speech_music"):
+        a, b = sorted(os.listdir(tmp_path / "feat_dev" / cls)), sorted(os.listdir(tmp_path / "feat_ref" / cls))
+        assert a == b and len(a) > 0
+        for f in a:
+            assert np.array_equal(np.load(tmp_path / "feat_dev" / cls / f), np.load(tmp_path / "feat_ref" / cls / f)), (cls, f)
+    # a second generator over the now cached features yields the same first batch (cache hits take the patch-only path)
+    np.random.seed(7)
+    again = next(gen.generator(Pd, folder, copy.deepcopy(files), 16))
+    assert np.max(np.abs(again[0].cpu().numpy() - got[0][0].cpu().numpy())) <= 2e-4
+    # ... and feeds model.fit directly
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
+    model, _ = get_Lemaire_MTL_model(TR_STEPS=2, N_MELS=240, n_classes=3, patch_size=68, seed=0)
+    h = model.fit(gen.generator(Pd, folder, copy.deepcopy(files), 16), steps_per_epoch=2, epochs=1, verbose=0)
+    assert np.isfinite(h.history["loss"]).all()
+
+
+def test_file_wise_generator_device_path(tmp_path):
+    from sm_hpss_mtl_amd import generators as gen
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    folder, files = _dataset(tmp_path)
+    P = _params(tmp_path, "feat")
+    sp, mu = folder + "/speech/" + files["speech"][2], folder + "/music/" + files["music"][1]
+    for args, lab in (((sp, "", None), 1), (("", mu, None), 0), ((sp, mu, 10), 2)):
+        x, y = gen.test_file_wise_generator(P, *args)
+        xr, yr = gen.test_file_wise_generator(P, *args, featuregram_fn=pp.get_featuregram, patches_fn=pp.get_feature_patches)
+        assert tuple(x.shape) == xr.shape and x.shape[1:] == (68, 240) and np.array_equal(y, yr) and np.all(y[:, lab] == 1)
+        assert np.max(np.abs(x.cpu().numpy() - xr)) <= 2e-4
+    assert not os.path.exists(tmp_path / "feat" / "speech")  # save_feat=False (Proposed_Work_Results.py:465-469)

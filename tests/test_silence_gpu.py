@@ -224,3 +224,19 @@ def test_error_behaviour(sil):
         sil.normalize(x.double())
     e = sil.rms(dev(np.zeros((0, 1000), np.float32)), 400, 160)
     assert e.shape == (0, 7)  # empty batch
+
+
+def test_mix_signals_host_call():
+    """lib.preprocessing.mix_signals(Xin_sp, Xin_mu, target_dB) (preprocessing.py:297-325): one pair = a batch of one on the
+    device; looped and cut music, against the oracle."""
+    from oracle import frontend as ofe
+    from sm_hpss_mtl_amd.lib import preprocessing as pp
+    rng = np.random.default_rng(1)
+    sp = rng.standard_normal(5000).astype(np.float32)
+    for n_mu in (1700, 5000, 9001):
+        mu = rng.standard_normal(n_mu).astype(np.float32)
+        for db in (-5, 0, 10, 20):
+            a, b = pp.mix_signals(sp, mu, db), ofe.mix_signals(sp, mu, db)
+            assert a.dtype == np.float32 and a.shape == (5000,)
+            np.testing.assert_allclose(a, b, atol=2e-6)
+            assert abs(np.max(np.abs(a)) - 1) < 1e-6

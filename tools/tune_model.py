@@ -7,13 +7,19 @@ N = 1024
 m = B3MTL(n_feat=240, patch_size=68, n_classes=3, seed=0)
 x = torch.randn((N, 68, 240), device="cuda")
 out = torch.empty((N, m.out_dim), device="cuda")
+X0 = os.environ.get("TUNE_X0") == "1"   # the bench path: start from the layer-0 partials (N, 2, 68, 32)
+x0p = torch.randn((N, 2, 68, 32), device="cuda")
+trunk = torch.empty((N, 68, 32), device="cuda")
+def fwd():
+    if X0: m.forward_from_x0(x0p, out=out, trunk=trunk)
+    else: m.forward_device(x, out=out)
 def t(nb, rounds=12):
     if nb is None: os.environ.pop("SMH_TCN_BLOCKS", None)
     else: os.environ["SMH_TCN_BLOCKS"] = str(nb)
     ts = []
     for _ in range(rounds):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); m.forward_device(x, out=out); b.record(); torch.cuda.synchronize()
+        a.record(); fwd(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     return float(np.median(ts[3:]))
 os.environ['SMH_TCN_NOHEADS']='1'
