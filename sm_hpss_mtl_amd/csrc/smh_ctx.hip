@@ -196,9 +196,10 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
         }
         auto weight = [&](int m, int k) { return c->n_mels > 0 ? mw[moff[m] + (k - st[m])] : 1.0f; };
         bool ok = true;
-        for (int v = 0; v < 2; ++v) {
-            int NS = v == 0 ? 4 : 8;  // 4 measured best of 3..8 for the two-kernel path at K = 201, T = 98
-            if (const char *ev = getenv(v == 0 ? "SMH_FEAT_SEGS" : "SMH_FEAT_SEGS1"))
+        c->feat_pend = 1;
+        for (int v = 0; v < 3; ++v) {
+            int NS = v == 0 ? 4 : (v == 1 ? 8 : 16);  // 4 measured best of 3..8 for the two-kernel path at K = 201, T = 98
+            if (const char *ev = getenv(v == 0 ? "SMH_FEAT_SEGS" : (v == 1 ? "SMH_FEAT_SEGS1" : "SMH_FEAT_SEGS2")))
                 NS = std::max(1, std::min(atoi(ev), (int)smh_ctx::kMaxFeatSegs));  // tuning
             int bound[smh_ctx::kMaxFeatSegs + 1];
             bound[0] = 0;
@@ -227,7 +228,7 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
                     for (int m = m0; m < m1; ++m)
                         if (st[m] <= k && k < en[m]) {
                             if (m < mcur || m > mcur + 3) ok = false;  // more than four pending filters, or out of order
-                            else w4[m - mcur] = weight(m, k);
+                            else w4[m - mcur] = weight(m, k), c->feat_pend = std::max(c->feat_pend, m - mcur + 1);
                         }
                     for (int e = 0; e < 4; ++e) plan.push_back(w4[e]);
                     float ne;

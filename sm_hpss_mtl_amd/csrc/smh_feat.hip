@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 
 #include "smh_common.h"
 #include "smh_feat.h"
@@ -304,7 +305,7 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
 // along frames, every element once; the time-major harm clip is copied to LDS (odd row stride) and read column-wise.
 // ---------------------------------------------------------------------------------------------------
 struct FeatPlan {
-    int nseg;
+    int nseg, pend;  // pend: most filters pending at any bin (2 or 4 accumulators)
     int m0[smh_ctx::kMaxFeatSegs], m1[smh_ctx::kMaxFeatSegs], kbeg[smh_ctx::kMaxFeatSegs], kend[smh_ctx::kMaxFeatSegs],
         off[smh_ctx::kMaxFeatSegs];
     const float *plan;
@@ -561,7 +562,7 @@ __global__ void clip_fv_kernel(float *__restrict__ fv, const int *__restrict__ m
 // LDS: image [2*rows][T|1] + 3 floats per row + 32 ints  (98 frames, 240 rows: 98 KB, one workgroup per CU).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const float *__restrict__ harmb,
+features_clip_kernel(FeatPlan fp, int log_db, int pair, int stop_after /* tuning: bits 0-3 phase probe, bit 4 no pipelining */, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
                      float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
                      float *__restrict__ x0p) {
@@ -573,15 +574,131 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
     float *s_inv = s_mean + R2, *s_lo = s_mean + 2 * R2;
     int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)R2);  // 32 ints
     float *w0s = s_mean + 3 * (size_t)R2 + 32;  // layer-0 weights [R2][32] (x0p only)
-    if (x0p)  // consumed after several barriers
-        for (int i = threadIdx.x; i < R2 * 32; i += blockDim.x) w0s[i] = w0[i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const size_t cb = (size_t)b * K * T;
     const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
-    float mxH = -FLT_MAX, mxP = -FLT_MAX;
+    float mxH = 0.f, mxP = 0.f;  // maxima of the filter sums (sums of non-negative terms)
 
+    // ---- the bin walk, lane = PAIR of frames (even T): every load is 8 bytes, the masks and the filter sums run on packed
+    // f32 instructions (v_pk_mul / v_pk_add / v_pk_fma: two frames per VALU slot).  The soft masks are evaluated as
+    //   H = S h^2 / (h^2 + p^2),  P = S p^2 / (h^2 + p^2)        (one reciprocal per frame)
+    // which is librosa's m / (m + r) with m = (h/Z)^2, r = (p/Z)^2, Z = max(h, p) without the normalisation by Z; where
+    // h^2 + p^2 would leave the normal range (both medians below ~1e-15: digital silence) the wave takes the
+    // normalised form with its split_zeros rule instead (wave-uniform branch, practically never taken).
+    // The image receives the filter sums themselves (magnitudes); the dB conversion waits for the write phase below, where
+    // the VALU idles behind the stores (in the walk the four v_log per emitted pair were a third of the instruction slots).
+    // NP = pending filters per bin: 2 for every Slaney bank whose filters are at least as wide as they are apart (the
+    // reference's 120 mels over 201 bins: a frequency lies in exactly two triangles), 4 in general.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int npair = T >> 1;
+    const int nwp = (npair + 63) >> 6;
+    auto pair_walk = [&](auto np_c, auto pipe_c) {
+        constexpr int NP = decltype(np_c)::value;
+        constexpr bool PIPE = decltype(pipe_c)::value;
+        for (int task = wave; task < fp.nseg * nwp; task += nw) {
+            const int seg = __builtin_amdgcn_readfirstlane(task / nwp);
+            const int tw = task - seg * nwp;
+            const int l = tw * 64 + lane;
+            const bool active = l < npair;
+            const int t0 = 2 * min(l, npair - 1);
+            const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
+            int mcur = fp.m0[seg];
+            const float *plan = fp.plan + fp.off[seg];
+            f32x2 aH[NP], aP[NP];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) aH[e] = f32x2{0.f, 0.f}, aP[e] = f32x2{0.f, 0.f};
+            auto emit_first = [&]() {
+                const f32x2 vH = aH[0], vP = aP[0];
+                mxH = fmaxf(mxH, fmaxf(vH.x, vH.y)), mxP = fmaxf(mxP, fmaxf(vP.x, vP.y));
+                if (active) {
+                    float *oh = img + mcur * ld + t0, *op = img + (rows + mcur) * ld + t0;
+                    oh[0] = vH.x, oh[1] = vH.y;
+                    op[0] = vP.x, op[1] = vP.y;
+                }
+#pragma unroll
+                for (int e = 0; e + 1 < NP; ++e) aH[e] = aH[e + 1], aP[e] = aP[e + 1];
+                aH[NP - 1] = f32x2{0.f, 0.f}, aP[NP - 1] = f32x2{0.f, 0.f};
+                ++mcur;
+            };
+            const float *Sb = S + cb + t0, *Pb = perc + cb + t0;
+            const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
+            // Software pipeline over half-batches of kPB bins: the loads of the next half-batch are in flight while this one is
+            // computed.  (All 16 waves of the only workgroup a CU holds run the same program: with "load a batch, wait,
+            // compute" the CU alternated between a memory burst and a compute burst and the walk took their sum.)
+            constexpr int kPB = 4;
+            struct HalfBatch {
+                f32x2 sv[kPB], pv[kPB], hv[kPB];
+                float4 wq[kPB];
+                int ne[kPB];
+            };
+            auto load = [&](int k0, HalfBatch &hb) {
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) {
+                    const int kk = min(k0 + u, K - 1);
+                    hb.sv[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)kk * T);
+                    hb.pv[u] = *reinterpret_cast<const f32x2 *>(Pb + (size_t)kk * T);
+                    hb.hv[u] = *reinterpret_cast<const f32x2 *>(Hb + (size_t)kk * 16);
+                    const int pi = max(min(k0 + u, kend - 1) - kbeg, 0);
+                    hb.wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
+                    hb.ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
+                }
+            };
+            auto compute = [&](int k0, const HalfBatch &hb) {
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) {
+                    if (k0 + u >= kend) break;
+                    for (int i = 0; i < hb.ne[u]; ++i) emit_first();
+                    const f32x2 h2 = hb.hv[u] * hb.hv[u], p2 = hb.pv[u] * hb.pv[u];
+                    const f32x2 den = h2 + p2;
+                    f32x2 H, P;
+                    constexpr float kDenMin = 7.8886091e-31f;  // 2^-100
+                    if (__builtin_expect(__any(den.x < kDenMin || den.y < kDenMin), 0)) {
+                        float Hx, Px, Hy, Py;
+                        hpss_masks_fast(hb.sv[u].x, hb.hv[u].x, hb.pv[u].x, Hx, Px);
+                        hpss_masks_fast(hb.sv[u].y, hb.hv[u].y, hb.pv[u].y, Hy, Py);
+                        H = f32x2{Hx, Hy}, P = f32x2{Px, Py};
+                    } else {
+                        const f32x2 q = hb.sv[u] * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                        H = h2 * q, P = p2 * q;
+                    }
+                    aH[0] += hb.wq[u].x * H, aP[0] += hb.wq[u].x * P;
+                    aH[1] += hb.wq[u].y * H, aP[1] += hb.wq[u].y * P;
+                    if constexpr (NP > 2) {
+                        aH[2] += hb.wq[u].z * H, aP[2] += hb.wq[u].z * P;
+                        aH[3] += hb.wq[u].w * H, aP[3] += hb.wq[u].w * P;
+                    }
+                }
+            };
+            HalfBatch b0, b1;
+            if constexpr (PIPE) {
+                load(kbeg, b0);
+                for (int k0 = kbeg; k0 < kend; k0 += 2 * kPB) {
+                    load(k0 + kPB, b1);
+                    compute(k0, b0);
+                    load(k0 + 2 * kPB, b0);
+                    compute(k0 + kPB, b1);
+                }
+            } else {
+                for (int k0 = kbeg; k0 < kend; k0 += 2 * kPB) {
+                    load(k0, b0);
+                    load(k0 + kPB, b1);
+                    compute(k0, b0);
+                    compute(k0 + kPB, b1);
+                }
+            }
+            while (mcur < m1) emit_first();
+        }
+    };
+    if (pair) {
+        if (fp.pend <= 2) {
+            if (stop_after & 16) pair_walk(std::integral_constant<int, 2>{}, std::false_type{});
+            else pair_walk(std::integral_constant<int, 2>{}, std::true_type{});
+        } else pair_walk(std::integral_constant<int, 4>{}, std::true_type{});
+    }
+    stop_after &= 15;
+    // ---- the bin walk, lane = frame (odd T) ----
     const int nwt = (T + 63) >> 6;
-    for (int task = wave; task < fp.nseg * nwt; task += nw) {
+    for (int task = wave; !pair && task < fp.nseg * nwt; task += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(task / nwt);
         const int tw = task - seg * nwt;
         const int t = tw * 64 + lane;
@@ -592,11 +709,8 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         const float *plan = fp.plan + fp.off[seg];
         float aH[4] = {0.f, 0.f, 0.f, 0.f}, aP[4] = {0.f, 0.f, 0.f, 0.f};
         auto emit_first = [&]() {
-            float vH = aH[0], vP = aP[0];
-            if (log_db) {
-                vH = db_of_sq_fast(vH), vP = db_of_sq_fast(vP);
-                mxH = fmaxf(mxH, vH), mxP = fmaxf(mxP, vP);
-            }
+            const float vH = aH[0], vP = aP[0];
+            mxH = fmaxf(mxH, vH), mxP = fmaxf(mxP, vP);
             if (active) {
                 img[mcur * ld + tc] = vH;
                 img[(rows + mcur) * ld + tc] = vP;
@@ -636,8 +750,11 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         }
         while (mcur < m1) emit_first();
     }
-    // per-array maximum -> top_db thresholds
-    float thrH = -FLT_MAX, thrP = -FLT_MAX;
+    if (x0p)  // layer-0 weights -> LDS; consumed after several barriers, fetched behind the walk's own loads
+        for (int i = threadIdx.x; i < R2 * 32; i += blockDim.x) w0s[i] = w0[i];
+    // per-array maximum of the filter sums -> the top_db floor in the power domain:
+    //   max(10 log10(max(amin, x^2)), dBmax - 80) = 10 log10(max(amin, x^2, max(amin, xmax^2) * 1e-8))       (log is monotone)
+    float limH = 0.f, limP = 0.f;
     {
         int kH = ordered_key(mxH), kP = ordered_key(mxP);
         for (int off = 32; off > 0; off >>= 1) {
@@ -646,20 +763,22 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         }
         if (lane == 0) smax[wave] = kH, smax[16 + wave] = kP;
         __syncthreads();  // also: the image is complete
+        if (stop_after == 1) return;  // tuning probes (SMH_FEAT_STOP): time the kernel phase by phase
         if (log_db) {
             int a = smax[0], c = smax[16];
             for (int q = 1; q < nw; ++q) a = max(a, smax[q]), c = max(c, smax[16 + q]);
-            thrH = key_to_float(a) - kTopDb, thrP = key_to_float(c) - kTopDb;
+            const float xh = key_to_float(a), xp = key_to_float(c);
+            limH = fmaxf(kAmin, fmaxf(kAmin, xh * xh) * 1e-8f), limP = fmaxf(kAmin, fmaxf(kAmin, xp * xp) * 1e-8f);
         }
     }
-    // clip in LDS, write the final featuregram (coalesced rows)
+    // dB + clip in LDS (the image becomes the final featuregram), write it out (coalesced rows)
+    auto final_value = [&](float x, float lim) { return log_db ? 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(x * x, lim)) : x; };
     float *g = fv + (size_t)b * R2 * T;
     if ((T & 1) == 0) {  // rows start on 8-byte boundaries: one float2 per lane, a 98-frame row is one instruction
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         for (int r = wave; r < R2; r += nw) {
-            const float thr = r < rows ? thrH : thrP;
+            const float lim = r < rows ? limH : limP;
             for (int t2 = lane; t2 < T / 2; t2 += 64) {
-                const float x0 = fmaxf(img[r * ld + 2 * t2], thr), x1 = fmaxf(img[r * ld + 2 * t2 + 1], thr);
+                const float x0 = final_value(img[r * ld + 2 * t2], lim), x1 = final_value(img[r * ld + 2 * t2 + 1], lim);
                 img[r * ld + 2 * t2] = x0;
                 img[r * ld + 2 * t2 + 1] = x1;
                 f32x2 v = {x0, x1};
@@ -668,16 +787,16 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         }
     } else {
         for (int r = wave; r < R2; r += nw) {
-            const float thr = r < rows ? thrH : thrP;
+            const float lim = r < rows ? limH : limP;
             for (int t = lane; t < T; t += 64) {
-                const float x = fmaxf(img[r * ld + t], thr);
+                const float x = final_value(img[r * ld + t], lim);
                 img[r * ld + t] = x;
                 g[(size_t)r * T + t] = x;
             }
         }
     }
     __syncthreads();
-    if ((!patches && !x0p) || nP <= 0) return;
+    if ((!patches && !x0p) || nP <= 0 || stop_after == 2) return;
     // StandardScaler statistics: one thread per row, f64 (see std_patch_kernel)
     for (int r0 = 0; r0 < R2; r0 += (int)(blockDim.x >> 2)) {  // four lanes per row, f64 partial sums
         const int r = r0 + (int)(threadIdx.x >> 2), sub = threadIdx.x & 3;
@@ -707,6 +826,7 @@ features_clip_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const
         s_lo[r] = (float)(mean - (double)(float)mean);
     }
     __syncthreads();
+    if (stop_after == 3) return;
     if (x0p) {
         // The network's first layer, per clip half (std_patch_kernel<true> has the derivation):
         // x0p[half][t][c] = sum_r W0[half*rows + r][c] * standardised(img[half*rows + r][t]).  One task = one 16-frame tile
@@ -784,6 +904,240 @@ __global__ void fill_int_kernel(int *p, int n, int v) {
     if (i < n) p[i] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// features_half_kernel: the single-kernel feature path with ONE WORKGROUP PER (clip, half) -- harmonic rows or
+// percussive rows -- instead of one per clip.  Everything behind the masks is per half anyway (the top-dB maximum is
+// taken per H / P array, lib/preprocessing.py:420,422; StandardScaler runs per half, :211-224; the layer-0 partials
+// are per half), so the two halves need nothing from each other.  What the split buys: the LDS image is 47 KB instead
+// of 94 KB, so TWO workgroups share a CU and one's memory phases (the walk streams 236 KB, the featuregram write) run
+// beside the other's arithmetic phases (statistics, layer 0) -- with one workgroup per CU the kernel was the plain sum of
+// its phases.  What it costs: both halves stream S / harm / perc (the second read comes from L2: the two
+// workgroups of a clip sit on the same XCD, 8 dispatch slots apart) and evaluate the mask denominator.
+// Even T only (lane = frame pair, packed f32 arithmetic, see features_clip_kernel); odd T keeps features_clip_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ void __launch_bounds__(512)
+features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__restrict__ S, const float *__restrict__ harmb,
+                     const float *__restrict__ perc, int B, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
+                     float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
+                     float *__restrict__ x0p) {
+    extern __shared__ __attribute__((aligned(16))) float img[];  // [rows][ld]
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // blocks i and i + 8 share an XCD (round-robin dispatch): clip 8 g + r, half h  <->  block 16 g + 8 h + r
+    const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
+    const int half = rr >> 3, b = grp * 8 + (rr & 7);
+    if (b >= B) return;
+    const int ld = T | 1, R2 = 2 * rows;
+    float *s_mean = img + (size_t)rows * ld;  // mean hi [rows], 1/scale [rows], mean lo [rows]
+    float *s_inv = s_mean + rows, *s_lo = s_mean + 2 * rows;
+    int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)rows);  // 16 ints
+    float *w0s = s_mean + 3 * (size_t)rows + 16;  // this half's layer-0 weights [rows][32] (x0p only)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const size_t cb = (size_t)b * K * T;
+    const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
+    float mx = 0.f;  // maximum of this half's filter sums (sums of non-negative terms)
+
+    const int npair = T >> 1;
+    const int nwp = (npair + 63) >> 6;
+    for (int task = wave; task < fp.nseg * nwp; task += nw) {
+        const int seg = __builtin_amdgcn_readfirstlane(task / nwp);
+        const int tw = task - seg * nwp;
+        const int l = tw * 64 + lane;
+        const bool active = l < npair;
+        const int t0 = 2 * min(l, npair - 1);
+        const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
+        int mcur = fp.m0[seg];
+        const float *plan = fp.plan + fp.off[seg];
+        f32x2 acc[NP];
+#pragma unroll
+        for (int e = 0; e < NP; ++e) acc[e] = f32x2{0.f, 0.f};
+        auto emit_first = [&]() {
+            const f32x2 v = acc[0];
+            mx = fmaxf(mx, fmaxf(v.x, v.y));
+            if (active) {
+                float *o = img + mcur * ld + t0;
+                o[0] = v.x, o[1] = v.y;
+            }
+#pragma unroll
+            for (int e = 0; e + 1 < NP; ++e) acc[e] = acc[e + 1];
+            acc[NP - 1] = f32x2{0.f, 0.f};
+            ++mcur;
+        };
+        // "own" = the median this half's mask favours (harm for H, perc for P): out = S own^2 / (own^2 + other^2)
+        const float *Sb = S + cb + t0, *Pb = perc + cb + t0;
+        const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
+        for (int k0 = kbeg; k0 < kend; k0 += kWalkBatch) {
+            f32x2 sv[kWalkBatch], pv[kWalkBatch], hv[kWalkBatch];
+            float4 wq[kWalkBatch];
+            int ne[kWalkBatch];
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                const int kk = min(k0 + u, K - 1);
+                sv[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)kk * T);
+                pv[u] = *reinterpret_cast<const f32x2 *>(Pb + (size_t)kk * T);
+                hv[u] = *reinterpret_cast<const f32x2 *>(Hb + (size_t)kk * 16);
+                const int pi = min(k0 + u, kend - 1) - kbeg;
+                wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
+                ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < kWalkBatch; ++u) {
+                if (k0 + u >= kend) break;
+                for (int i = 0; i < ne[u]; ++i) emit_first();
+                const f32x2 own = half ? pv[u] : hv[u], oth = half ? hv[u] : pv[u];
+                const f32x2 o2 = own * own;
+                const f32x2 den = o2 + oth * oth;
+                f32x2 X;
+                constexpr float kDenMin = 7.8886091e-31f;  // 2^-100
+                if (__builtin_expect(__any(den.x < kDenMin || den.y < kDenMin), 0)) {
+                    float Hx, Px, Hy, Py;
+                    hpss_masks_fast(sv[u].x, hv[u].x, pv[u].x, Hx, Px);
+                    hpss_masks_fast(sv[u].y, hv[u].y, pv[u].y, Hy, Py);
+                    X = half ? f32x2{Px, Py} : f32x2{Hx, Hy};
+                } else {
+                    X = o2 * (sv[u] * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
+                }
+                acc[0] += wq[u].x * X;
+                acc[1] += wq[u].y * X;
+                if constexpr (NP > 2) {
+                    acc[2] += wq[u].z * X;
+                    acc[3] += wq[u].w * X;
+                }
+            }
+        }
+        while (mcur < m1) emit_first();
+    }
+    if (x0p)  // this half's layer-0 weights -> LDS; consumed after several barriers
+        for (int i = threadIdx.x; i < rows * 32; i += blockDim.x) w0s[i] = w0[(size_t)half * rows * 32 + i];
+    // maximum of the array -> the top_db floor in the power domain (see features_clip_kernel)
+    float lim = 0.f;
+    {
+        int kx = ordered_key(mx);
+        for (int off = 32; off > 0; off >>= 1) kx = max(kx, __shfl_xor(kx, off));
+        if (lane == 0) smax[wave] = kx;
+        __syncthreads();  // also: the image is complete
+        if (stop_after == 1) return;
+        if (log_db) {
+            int a = smax[0];
+            for (int q = 1; q < nw; ++q) a = max(a, smax[q]);
+            const float xm = key_to_float(a);
+            lim = fmaxf(kAmin, fmaxf(kAmin, xm * xm) * 1e-8f);
+        }
+    }
+    // dB + clip in LDS (the image becomes this half of the final featuregram), write it out (coalesced rows)
+    float *g = fv + ((size_t)b * R2 + (size_t)half * rows) * T;
+    for (int r = wave; r < rows; r += nw) {
+        for (int t2 = lane; t2 < T / 2; t2 += 64) {
+            float x0 = img[r * ld + 2 * t2], x1 = img[r * ld + 2 * t2 + 1];
+            if (log_db) {
+                x0 = 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(x0 * x0, lim));
+                x1 = 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(x1 * x1, lim));
+            }
+            img[r * ld + 2 * t2] = x0;
+            img[r * ld + 2 * t2 + 1] = x1;
+            f32x2 v = {x0, x1};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(g + (size_t)r * T) + t2);
+        }
+    }
+    __syncthreads();
+    if ((!patches && !x0p) || nP <= 0 || stop_after == 2) return;
+    // StandardScaler statistics: four lanes per row, f64 partial sums (see std_patch_kernel)
+    for (int r0 = 0; r0 < rows; r0 += (int)(blockDim.x >> 2)) {
+        const int r = r0 + (int)(threadIdx.x >> 2), sub = threadIdx.x & 3;
+        const bool on = r < rows;
+        const float *row = img + (on ? r : 0) * ld;
+        double sum = 0.0;
+        for (int t = sub; t < T; t += 4) sum += (double)row[t];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const double mean = sum / (double)T;
+        double qv = 0.0;
+        for (int t = sub; t < T; t += 4) {
+            const double dlt = (double)row[t] - mean;
+            qv += dlt * dlt;
+        }
+        qv += __shfl_xor(qv, 1);
+        qv += __shfl_xor(qv, 2);
+        if (!on || sub != 0) continue;
+        const double var = qv / (double)T;
+        const double eps = 2.220446049250313e-16;
+        const double nm = (double)T * mean * eps;
+        const bool constant = var <= (double)T * eps * var + nm * nm;
+        double scale = sqrt(var);
+        if (constant || scale == 0.0) scale = 1.0;
+        s_mean[r] = (float)mean;
+        s_inv[r] = (float)(1.0 / scale);
+        s_lo[r] = (float)(mean - (double)(float)mean);
+    }
+    __syncthreads();
+    if (stop_after == 3) return;
+    if (x0p) {
+        // this half's share of the network's first layer (features_clip_kernel has the derivation); one task = one 16-frame
+        // tile with both 16-channel M-tiles
+        const int q = lane >> 4, j = lane & 15;
+        const int ut = (W + 15) >> 4;
+        const int nst = rows / 4;
+        for (int task = wave; task < nP * ut; task += nw) {
+            const int p = task / ut, u = task - p * ut;
+            int s = p * shift;
+            const int e = min(s + W, Ttiled);
+            if (e - s < W) s = e - W;
+            const int jt = 16 * u + j;
+            int tt = s + min(jt, W - 1);
+            tt -= (tt / T) * T;
+            const float *wr = w0s + (size_t)q * 32 + j;
+            const float *tl = img + tt;
+            f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = c0a, c1a = c0a, c1b = c0a;  // two chains per M-tile
+            for (int s0 = 0; s0 < nst; s0 += 8) {
+                float xs[8], is[8], wa0[8], wa1[8], hs[8], ls[8];
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const int r = 4 * min(s0 + g8, nst - 1) + q;
+                    xs[g8] = tl[r * ld];
+                    hs[g8] = s_mean[r], ls[g8] = s_lo[r];
+                    is[g8] = s0 + g8 < nst ? s_inv[r] : 0.f;
+                    wa0[g8] = wr[(size_t)(r - q) * 32];
+                    wa1[g8] = wr[(size_t)(r - q) * 32 + 16];
+                }
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const float c = __fsub_rn(__fsub_rn(xs[g8], hs[g8]), ls[g8]) * is[g8];
+                    if (g8 & 1) {
+                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[g8], c, c0b, 0, 0, 0);
+                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[g8], c, c1b, 0, 0, 0);
+                    } else {
+                        c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[g8], c, c0a, 0, 0, 0);
+                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[g8], c, c1a, 0, 0, 0);
+                    }
+                }
+            }
+            c0a += c0b, c1a += c1b;
+            if (jt < W) {
+                float *o = x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q;
+                *reinterpret_cast<f32x4 *>(o) = c0a;
+                *reinterpret_cast<f32x4 *>(o + 16) = c1a;
+            }
+        }
+    }
+    if (!patches) return;
+    for (int p = 0; p < nP; ++p) {
+        int s0 = p * shift;
+        const int e = min(s0 + W, Ttiled);
+        if (e - s0 < W) s0 = e - W;
+        float *o = patches + ((size_t)b * nP + p) * W * R2 + (size_t)half * rows;
+        for (int j = wave; j < W; j += nw) {  // one wave per frame: lanes over this half's features
+            int tt = s0 + j;
+            tt -= (tt / T) * T;
+            for (int f = lane; f < rows; f += 64) {
+                const float c = (float)((double)img[f * ld + tt] - ((double)s_mean[f] + (double)s_lo[f]));
+                o[(size_t)j * R2 + f] = c * s_inv[f];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace smh_feat {
@@ -811,7 +1165,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     const int walk_waves = c->feat_nseg[0] * ((T + 63) / 64);
     if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !getenv("SMH_FEAT_TAPS")) {
         FeatPlan fp;
-        fp.nseg = c->feat_nseg[0];
+        fp.nseg = c->feat_nseg[0], fp.pend = c->feat_pend;
         for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
             fp.m0[i] = c->feat_m0[0][i], fp.m1[i] = c->feat_m1[0][i], fp.kbeg[i] = c->feat_kbeg[0][i],
             fp.kend[i] = c->feat_kend[0][i], fp.off[i] = c->feat_off[0][i];
@@ -842,14 +1196,36 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
     size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
     if (x0p) lds += sizeof(float) * 2 * rows * 32;  // the layer's weights
     if (lds > 158 * 1024) return 0;
+    // even T: lane = frame pair over the 16-segment plan (packed f32 arithmetic); odd T: lane = frame, 8 segments
+    const int pair = (T % 2 == 0 && c->feat_nseg[2] > 0 && !getenv("SMH_FEAT_NOPAIR")) ? 1 : 0;
+    const int v = pair ? 2 : 1;
     FeatPlan fp;
-    fp.nseg = c->feat_nseg[1];
+    fp.nseg = c->feat_nseg[v], fp.pend = c->feat_pend;
     for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
-        fp.m0[i] = c->feat_m0[1][i], fp.m1[i] = c->feat_m1[1][i], fp.kbeg[i] = c->feat_kbeg[1][i],
-        fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
+        fp.m0[i] = c->feat_m0[v][i], fp.m1[i] = c->feat_m1[v][i], fp.kbeg[i] = c->feat_kbeg[v][i],
+        fp.kend[i] = c->feat_kend[v][i], fp.off[i] = c->feat_off[v][i];
     fp.plan = c->d_feat_plan;
+    const char *stop_ev = getenv("SMH_FEAT_STOP");  // tuning only
+    const int stop = stop_ev ? atoi(stop_ev) : 0;
+    if (pair && !getenv("SMH_FEAT_NOSPLIT")) {
+        // one workgroup per (clip, half): half the LDS, two workgroups per CU (features_half_kernel)
+        size_t ldh = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows) + 64;
+        if (x0p) ldh += sizeof(float) * rows * 32;
+        const unsigned grid = 16u * (unsigned)((B + 7) / 8);
+        if (fp.pend <= 2) {
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
+            hipLaunchKernelGGL(features_half_kernel<2>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, B, K, T,
+                               rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
+        } else {
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
+            hipLaunchKernelGGL(features_half_kernel<4>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, B, K, T,
+                               rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
+        }
+        int rch = smh::launch_status("features_half_kernel");
+        return rch ? rch : 1;
+    }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, S, harmb, perc, K, T, rows,
+    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, pair, stop, S, harmb, perc, K, T, rows,
                        smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
     int rc = smh::launch_status("features_clip_kernel");
     return rc ? rc : 1;
