@@ -215,7 +215,17 @@ typedef struct smh_model_cfg {
     int32_t kernel_size;/* 3                                                           */
     int32_t nb_stacks;  /* 3                                                           */
     int32_t n_dilations;/* 8 -> dilations 1,2,...,128                                  */
+    int32_t block_variant; /* residual block of the third-party `tcn.TCN` (lib/proposed_architectures.py:124-144), which the
+                            * reference does not pin: 0 = keras-tcn 2.3.x (initial 1x1 conv; per block dilated conv -> relu ->
+                            * channel-max normalisation ('norm_relu') -> dropout -> 1x1 conv -> + input; final relu) -- the API
+                            * the reference's positional call binds under, the default, training and the fused bench path;
+                            * 1 = keras-tcn >= 2.8 (no initial conv; per block two dilated convs, relu each, shortcut = input or
+                            * a 1x1 'matching' conv, relu of the sum) -- inference forward only (smh_model_forward_f32).
+                            * Canonical weight order for 1: per block [conv0 kernel (3,Cin,32), bias, conv1 kernel (3,32,32),
+                            * bias, (first block: matching kernel (1,n_feat,32), bias)], then '3C' and the heads as for 0. */
 } smh_model_cfg;
+#define SMH_TCN_BLOCK_2_3 0
+#define SMH_TCN_BLOCK_2_8 1
 
 int smh_model_create(const smh_model_cfg *cfg, smh_model **out);
 void smh_model_destroy(smh_model *m);

@@ -158,11 +158,62 @@ def mtl_heads(flat, w, n_classes: int = 3):
     return outs
 
 
+# ---------------------------------------------------------------------------------------------------
+# The later keras-tcn residual block (2.8 / 3.x), kept selectable because the reference does not pin keras-tcn:
+#   ResidualBlock(dilation d):  y = x
+#       for k in (0, 1):  y = Conv1D(nb_filters, kernel_size, dilation_rate=d, padding)(y);  y = relu(y);  SpatialDropout1D
+#       shortcut = x if channels match else Conv1D(nb_filters, 1, 'same')(x)          ('matching_conv1D', first block only)
+#       out = relu(shortcut + y)
+#   TCN: no initial 1x1 convolution, no final activation of its own; with use_skip_connections=False and
+#   return_sequences=True the output is the last block's `out`.   [recollection of the published keras-tcn source; "parity
+#   unpinned".  NB that release line dropped the 'norm_relu' activation and moved `activation` behind `padding` in the
+#   signature, so the reference's positional call (proposed_architectures.py:144) only binds under the 2.3.x API restated
+#   above -- block_variant 1 exists for a maintainer who ports that one call, not because the reference can run on it.]
+# ---------------------------------------------------------------------------------------------------
+def init_weights_v2(seed: int = 0, n_feat: int = 240, patch_size: int = 68, n_classes: int = 3, nb_filters: int = 32,
+                    kernel_size: int = 3, nb_stacks: int = 3, n_dil: int = 8, randomize_bn: bool = False):
+    rng = np.random.default_rng(seed)
+    C = nb_filters
+    w = {}
+    cin = n_feat
+    for s in range(nb_stacks):
+        for i in range(n_dil):
+            p = f"tcn/s{s}_d{2 ** i}"
+            w[p + "/conv0/kernel"] = _glorot(rng, (kernel_size, cin, C), kernel_size * cin, kernel_size * C)
+            w[p + "/conv0/bias"] = np.zeros(C, np.float32)
+            w[p + "/conv1/kernel"] = _glorot(rng, (kernel_size, C, C), kernel_size * C, kernel_size * C)
+            w[p + "/conv1/bias"] = np.zeros(C, np.float32)
+            if cin != C:
+                w[p + "/matching/kernel"] = _glorot(rng, (1, cin, C), cin, C)
+                w[p + "/matching/bias"] = np.zeros(C, np.float32)
+            cin = C
+    init_head_weights(w, rng, patch_size * C, n_classes)
+    if randomize_bn:
+        for k in w:
+            if k.endswith("/bias") or k.endswith("/beta") or k.endswith("moving_mean"):
+                w[k] = rng.normal(0, 0.1, size=w[k].shape).astype(np.float32)
+            elif k.endswith("/gamma") or k.endswith("moving_variance"):
+                w[k] = rng.uniform(0.5, 1.5, size=w[k].shape).astype(np.float32)
+    return w
+
+
+def tcn_forward_v2(x, w, nb_stacks=3, n_dil=8):
+    for s in range(nb_stacks):
+        for i in range(n_dil):
+            d, p = 2 ** i, f"tcn/s{s}_d{2 ** i}"
+            y = np.maximum(conv1d_same(x, w[p + "/conv0/kernel"], w[p + "/conv0/bias"], d), np.float32(0))
+            y = np.maximum(conv1d_same(y, w[p + "/conv1/kernel"], w[p + "/conv1/bias"], d), np.float32(0))
+            sc = conv1d_same(x, w[p + "/matching/kernel"], w[p + "/matching/bias"]) if (p + "/matching/kernel") in w else x
+            x = np.maximum((sc + y).astype(np.float32), np.float32(0))
+    return x
+
+
 def forward(x, w, n_classes: int = 3, return_trunk: bool = False):
     """Inference forward.  x: (N, T, F) float32.  Returns list in Keras output order
-    [S, M, (N,) R, 3C] (proposed_architectures.py:154)."""
+    [S, M, (N,) R, 3C] (proposed_architectures.py:154).  The residual-block variant follows the weights: dicts from
+    `init_weights_v2` (tensors '.../conv0/kernel') take the two-convolution block."""
     x = np.asarray(x, dtype=np.float32)
-    trunk = tcn_forward(x, w)
+    trunk = tcn_forward_v2(x, w) if "tcn/s0_d1/conv0/kernel" in w else tcn_forward(x, w)
     flat = trunk.reshape(trunk.shape[0], -1)  # Flatten: (T, C) row-major
     outs = mtl_heads(flat, w, n_classes)
     if return_trunk:

@@ -19,7 +19,7 @@ class FrontendCfg(C.Structure):
 class ModelCfg(C.Structure):
     _fields_ = [("n_feat", C.c_int32), ("patch_size", C.c_int32), ("n_classes", C.c_int32),
                 ("nb_filters", C.c_int32), ("kernel_size", C.c_int32), ("nb_stacks", C.c_int32),
-                ("n_dilations", C.c_int32)]
+                ("n_dilations", C.c_int32), ("block_variant", C.c_int32)]
 
 
 class CnnCfg(C.Structure):

@@ -82,4 +82,6 @@ void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
 int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
                    hipStream_t st, int from_x0 = 0);
+// smh_model_cfg.block_variant = 1 (smh_tcn_v2.hip): the two-convolution residual block of keras-tcn >= 2.8, inference only
+int launch_forward_v2(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, hipStream_t st);
 }  // namespace smh_tcn

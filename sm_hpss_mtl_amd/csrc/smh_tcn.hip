@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "smh_model.h"
+#include "smh_tcn_heads.h"
 
 using namespace smh_tcn;
 
@@ -409,125 +410,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     }
     __syncthreads();
 
-    // ---- Dense layers on the flattened trunk: pre[g][o] = sum_k flat[g][k] * Wh[k][o], k = t*32 + c, o < NH (51 or 69) ----
-    // On the VALU, not on the matrix cores: with 4 patches per workgroup a 16-column MFMA tile is 75 % padding, and exact-f32
-    // MFMA has the same peak as v_fma_f32 -- the padded product cost 4x the arithmetic (and ran at 17 us per launch,
-    // waiting for its weights).  Here a lane owns one output (two when NH > 64), a wave owns a range of frames; per frame
-    // it streams 32 rows of Wh (256 contiguous bytes per row and wave) and multiplies them with the four patches'
-    // activations, which are wave-uniform LDS reads.  The waves' partial sums meet in LDS.
-    const int OPL = (a.NH + 63) >> 6;           // outputs per lane
-    const int ld = OPL * 64;                    // row length of the packed weights Wh[k][ld]
-    // The frames are cut into kDenseParts fixed ranges (a function of T alone) and the ranges are summed in a fixed order, so
-    // a patch gets the same bits whatever the batch size, the patches per workgroup or the number of waves.
-    constexpr int kDenseParts = 8;
-    float *part = xout;                         // [kDenseParts][4][ld] partial sums, then pre[kMaxG][kPS] behind them
-    float *pre = xout + (size_t)kDenseParts * 4 * ld;
-    const int rpp = (T + kDenseParts - 1) / kDenseParts;
-    auto dense_on_trunk = [&](auto opl_c) {
-        constexpr int kOPL = decltype(opl_c)::value;
-        for (int g0 = 0; g0 < g_here; g0 += 4) {
-            const float *xg[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xg[g] = xin + (size_t)min(g0 + g, g_here - 1) * T * SX;
-            for (int pt = wave; pt < kDenseParts; pt += nw) {
-                const int t_lo = min(T, pt * rpp), t_hi = min(T, t_lo + rpp);
-                float acc[4][kOPL];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int p = 0; p < kOPL; ++p) acc[g][p] = 0.f;
-                for (int t = t_lo; t < t_hi; ++t) {
-                    const float *wrow = WhA + (size_t)t * C * ld + lane;
-#pragma unroll 1
-                    for (int c8 = 0; c8 < 4; ++c8) {
-                        float wv[8][kOPL];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c)
-#pragma unroll
-                            for (int p = 0; p < kOPL; ++p) wv[c][p] = wrow[(size_t)(8 * c8 + c) * ld + 64 * p];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 xa = *reinterpret_cast<const f32x4 *>(xg[g] + (size_t)t * SX + 8 * c8);
-                            const f32x4 xb = *reinterpret_cast<const f32x4 *>(xg[g] + (size_t)t * SX + 8 * c8 + 4);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                                for (int p = 0; p < kOPL; ++p) {
-                                    acc[g][p] = fmaf(xa[c], wv[c][p], acc[g][p]);
-                                    acc[g][p] = fmaf(xb[c], wv[4 + c][p], acc[g][p]);
-                                }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int p = 0; p < kOPL; ++p) part[((size_t)pt * 4 + g) * ld + 64 * p + lane] = acc[g][p];
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < 4 * ld; i += blockDim.x) {  // ordered sum over the parts: deterministic
-                const int g = i / ld, o = i - g * ld;
-                if (g0 + g < g_here && o < kPS) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int pt = 0; pt < kDenseParts; ++pt) v += part[((size_t)pt * 4 + g) * ld + o];
-                    pre[(g0 + g) * kPS + o] = v;
-                }
-            }
-            __syncthreads();
-        }
-    };
-    if (!a.skip_heads) {
-        if (OPL == 1) dense_on_trunk(std::integral_constant<int, 1>{});
-        else dense_on_trunk(std::integral_constant<int, 2>{});
-    }
-    // ---- BN / relu / output Dense / activations: one thread per (patch, head), one per patch for 3C ----
-    const float *bh = WhA + (size_t)a.D * ld;  // NH biases follow the packed weights
-    if constexpr (TRAIN) {  // training: the batch-statistics heads run in smh_train.hip on `pre`
-        for (int i = threadIdx.x; i < g_here * kPS; i += blockDim.x) {
-            const int p = i / kPS, o = i - p * kPS;
-            tio.pre[(size_t)(n0 + p) * kPS + o] = o < a.NH ? pre[p * kPS + o] + bh[o] : 0.f;
-        }
-        return;
-    }
-    const int tid = threadIdx.x;
-    if (tid < g_here * a.n_heads) {
-        const int p = tid / a.n_heads, h = tid - p * a.n_heads;
-        const float *ph = hp;
-        int col = 0;
-        for (int k = 0; k < h; ++k) {
-            ph += 4 * kHidden + kHidden * a.head_odim[k] + a.head_odim[k];
-            col += a.head_odim[k];
-        }
-        const float *gamma = ph, *beta = ph + 16, *mean = ph + 32, *var = ph + 48, *wo = ph + 64;
-        const int od = a.head_odim[h];
-        const float *bo = wo + kHidden * od;
-        float hid[kHidden];
-#pragma unroll
-        for (int i = 0; i < kHidden; ++i) {
-            const int o = a.n_classes + h * kHidden + i;
-            float v = pre[p * kPS + o] + bh[o];
-            v = (v - mean[i]) / sqrtf(var[i] + kBnEps);
-            v = v * gamma[i] + beta[i];
-            hid[i] = fmaxf(v, 0.f);
-        }
-        for (int c = 0; c < od; ++c) {
-            float s = bo[c];
-#pragma unroll
-            for (int i = 0; i < kHidden; ++i) s = fmaf(hid[i], wo[i * od + c], s);
-            if (a.head_sigmoid[h]) s = 1.0f / (1.0f + expf(-s));
-            out[(size_t)(n0 + p) * a.out_dim + col + c] = s;
-        }
-    } else if (tid >= 128 && tid < 128 + g_here) {
-        const int p = tid - 128;
-        float mxl = -INFINITY;
-        for (int c = 0; c < a.n_classes; ++c) mxl = fmaxf(mxl, pre[p * kPS + c] + bh[c]);
-        float den = 0.f;
-        for (int c = 0; c < a.n_classes; ++c) den += expf(pre[p * kPS + c] + bh[c] - mxl);
-        const int col = a.out_dim - a.n_classes;
-        for (int c = 0; c < a.n_classes; ++c)
-            out[(size_t)(n0 + p) * a.out_dim + col + c] = expf(pre[p * kPS + c] + bh[c] - mxl) / den;
-    }
+    dense_and_heads<TRAIN>(a, xin, xout, WhA, hp, out, tio, n0, g_here);
 }
 
 // gather kernel: packed[i] = map[i] ? flat[map[i] - 1] : 0
@@ -551,6 +434,9 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
     W0.assign(m->nW0, 0.f), Wb.assign(m->nWb, 0.f), WhA.assign(m->nWhA, 0.f), hp.assign(m->nhp, 0.f);
     std::vector<float> Wh((size_t)D * NH, 0.f), bhv((size_t)m->n_mt * 16, 0.f);
     const float *p = h;
+    if (m->cfg.block_variant == 1) {  // smh_tcn_v2.hip reads the trunk from the canonical tensor: only the heads are packed
+        p += (size_t)3 * F * C + C + 3 * C * C + C + (size_t)F * C + C + (size_t)(m->n_blocks - 1) * 2 * (3 * C * C + C);
+    } else {
     for (int s = 0; s < FQ; ++s)
         for (int mt = 0; mt < 2; ++mt)
             for (int lane = 0; lane < 64; ++lane) {
@@ -588,6 +474,7 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
                 }
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64, b1, C * sizeof(float));
         std::memcpy(wb + 24 * 2 * 64 + 8 * 2 * 64 + 32, b2, C * sizeof(float));
+    }
     }
     const float *k3c = p;
     p += (size_t)D * ncls;
@@ -751,8 +638,11 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     m->out_dim = cfg->n_classes;
     for (int i = 0; i < m->n_heads; ++i) m->out_dim += m->head_odim[i];
     m->FQ = (cfg->n_feat + 3) / 4;
+    SMH_REQUIRE(cfg->block_variant == 0 || cfg->block_variant == 1, "block_variant must be 0 (keras-tcn 2.3.x) or 1 (>= 2.8)");
     size_t n = (size_t)cfg->n_feat * C + C;
     n += (size_t)m->n_blocks * (3 * C * C + C + C * C + C);
+    if (cfg->block_variant == 1)
+        n = (size_t)3 * cfg->n_feat * C + C + 3 * C * C + C + (size_t)cfg->n_feat * C + C + (size_t)(m->n_blocks - 1) * 2 * (3 * C * C + C);
     n += (size_t)m->D * cfg->n_classes + cfg->n_classes;
     for (int i = 0; i < m->n_heads; ++i)
         n += (size_t)m->D * kHidden + kHidden + 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
@@ -760,6 +650,7 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     SMH_REQUIRE(n < (1u << 24), "model too large for the float-encoded gather map");
     m->nW0 = (size_t)m->FQ * 2 * 64 + 32;
     m->nWb = (size_t)m->n_blocks * kBlockFloats;
+    if (cfg->block_variant == 1) m->nW0 = m->nWb = 0;
     m->nWhA = (size_t)m->D * 64 * ((m->NH + 63) / 64) + (size_t)m->n_mt * 16;
     m->nhp = 0;
     for (int i = 0; i < m->n_heads; ++i) m->nhp += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
@@ -821,12 +712,13 @@ extern "C" int smh_model_get_weights(const smh_model *m, float *h, size_t n, voi
 }
 
 extern "C" const float *smh_model_w0_ptr(const smh_model *m) {
-    return m ? m->d_flat + smh_tcn::offsets(m).w0_k : nullptr;
+    return (m && m->cfg.block_variant == 0) ? m->d_flat + smh_tcn::offsets(m).w0_k : nullptr;
 }
 
 extern "C" int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk,
                                         void *stream) {
     SMH_REQUIRE(m && d_x0p && d_out, "smh_model_forward_x0_f32: null argument");
+    SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_x0_f32: the layer-0 fusion exists for block_variant 0 only");
     SMH_REQUIRE(N >= 0, "smh_model_forward_x0_f32: N=%d", N);
     if (N == 0) return SMH_OK;
     return smh_tcn::launch_forward(m, d_x0p, N, d_out, d_trunk, nullptr, (hipStream_t)stream, 1);
@@ -837,5 +729,6 @@ extern "C" int smh_model_forward_f32(const smh_model *m, const float *d_x, int N
     SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_f32: null argument");
     SMH_REQUIRE(N >= 0, "smh_model_forward_f32: N=%d", N);
     if (N == 0) return SMH_OK;
+    if (m->cfg.block_variant == 1) return smh_tcn::launch_forward_v2(m, d_x, N, d_out, d_trunk, (hipStream_t)stream);
     return smh_tcn::launch_forward(m, d_x, N, d_out, d_trunk, nullptr, (hipStream_t)stream);
 }

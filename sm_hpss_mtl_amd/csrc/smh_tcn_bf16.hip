@@ -328,6 +328,7 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
 extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream) {
     SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_bf16: null argument");
     SMH_REQUIRE(N >= 0, "smh_model_forward_bf16: N=%d", N);
+    SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_bf16: built for block_variant 0 only");
     SMH_REQUIRE(m->cfg.n_feat <= 256, "smh_model_forward_bf16: n_feat=%d exceeds the 256 features of the bf16 layer-0 tiling",
                 m->cfg.n_feat);
     if (N == 0) return SMH_OK;

@@ -862,6 +862,7 @@ struct smh_trainer {
 
 extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out) {
     SMH_REQUIRE(m && out && max_batch >= 1, "smh_trainer_create: bad argument");
+    SMH_REQUIRE(m->cfg.block_variant == 0, "smh_trainer_create: training is built for block_variant 0 (keras-tcn 2.3.x) only");
     smh_trainer *t = new smh_trainer();
     t->m = m, t->max_batch = max_batch;
     const Offsets off = offsets(m);

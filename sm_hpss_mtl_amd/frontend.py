@@ -55,6 +55,20 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _out(out, key, shape, dtype, dev):
+    """A caller-supplied output tensor (steady-state loops allocate nothing) or a fresh one.  The C ABI receives raw
+    pointers without sizes, so a stale `out` dict from a smaller batch must never reach it: wrong shape / dtype / device
+    raises here."""
+    t = out.get(key) if out else None
+    if t is None:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError("out[%r] must be a contiguous %s tensor on %s" % (key, dtype, dev))
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("out[%r] has shape %s, this call writes %s" % (key, tuple(t.shape), tuple(shape)))
+    return t
+
+
 def _f32c(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError("%s must be a CUDA/HIP torch tensor" % name)
@@ -183,19 +197,17 @@ class Frontend:
         """(S, harm, perc) -> dict(fv[, patches]): masks + mel + dB, then standardise + time-major patches."""
         S, harm, perc = _f32c(S, "S"), _f32c(harm, "harm"), _f32c(perc, "perc")
         B, K, T = S.shape
-        out = {} if out is None else out
-        fv = out.get("fv")
-        if fv is None:
-            fv = torch.empty((B, 2 * self.rows, T), dtype=torch.float32, device=S.device)
+        dev = S.device
+        fv = _out(out, "fv", (B, 2 * self.rows, T), torch.float32, dev)
         nP, patches = 0, None
         if W is not None:
             nP = self.num_patches(T, W, shift)
-            patches = out.get("patches")
-            if patches is None:
-                patches = torch.empty((B * nP, W, 2 * self.rows), dtype=torch.float32, device=S.device)
-        keys = out.get("maxkeys")
+            patches = _out(out, "patches", (B * nP, W, 2 * self.rows), torch.float32, dev)
+        keys = (out or {}).get("maxkeys")
         if keys is None:
-            keys = torch.empty(2 * max(B, 1), dtype=torch.int32, device=S.device)
+            keys = torch.empty(2 * max(B, 1), dtype=torch.int32, device=dev)
+        elif not (keys.is_cuda and keys.dtype == torch.int32 and keys.numel() >= 2 * B and keys.is_contiguous()):
+            raise ValueError("out['maxkeys'] must be a contiguous int32 device tensor with at least 2*B = %d entries" % (2 * B))
         got = _lib.check(self.lib.smh_features_f32(self._h, _ptr(S), _ptr(harm), _ptr(perc), B, T, W or 0, shift or 0,
                                                    _ptr(fv), _ptr(patches) if nP else None, _ptr(keys), _stream()),
                          "smh_features_f32")
@@ -213,15 +225,16 @@ class Frontend:
             raise ValueError("model expects (W=%d, n_feat=%d), the front end produces (W=%d, n_feat=%d)"
                              % (model.patch_size, model.n_feat, W, 2 * self.rows))
         model._sync_weights()
-        out = {} if out is None else out
         nP = self.num_patches(T, W, shift)
         dev = S.device
-        fv = out.get("fv") if out.get("fv") is not None else torch.empty((B, 2 * self.rows, T), dtype=torch.float32, device=dev)
-        x0p = out.get("x0p") if out.get("x0p") is not None else torch.empty((B * nP, 2, W, 32), dtype=torch.float32, device=dev)
-        pt = None
-        if patches:
-            pt = out.get("patches") if out.get("patches") is not None else torch.empty((B * nP, W, 2 * self.rows), dtype=torch.float32, device=dev)
-        keys = out.get("maxkeys") if out.get("maxkeys") is not None else torch.empty(2 * max(B, 1), dtype=torch.int32, device=dev)
+        fv = _out(out, "fv", (B, 2 * self.rows, T), torch.float32, dev)
+        x0p = _out(out, "x0p", (B * nP, 2, W, 32), torch.float32, dev)
+        pt = _out(out, "patches", (B * nP, W, 2 * self.rows), torch.float32, dev) if patches else None
+        keys = (out or {}).get("maxkeys")
+        if keys is None:
+            keys = torch.empty(2 * max(B, 1), dtype=torch.int32, device=dev)
+        elif not (keys.is_cuda and keys.dtype == torch.int32 and keys.numel() >= 2 * B and keys.is_contiguous()):
+            raise ValueError("out['maxkeys'] must be a contiguous int32 device tensor with at least 2*B = %d entries" % (2 * B))
         got = _lib.check(self.lib.smh_features_l0_f32(
             self._h, _ptr(S), _ptr(harm), _ptr(perc), int(harm_layout), B, T, W, shift, _ptr(fv), _ptr(pt),
             C.c_void_p(self.lib.smh_model_w0_ptr(model._h)), _ptr(x0p), _ptr(keys), _stream()), "smh_features_l0_f32")

@@ -142,13 +142,19 @@ def split_name(tensor_name):
 
 def write_weights(path, weights, backend=b"tensorflow", keras_version=b"2.4.0"):
     """weights: ordered mapping canonical tensor name -> float32 array.  Writes a Keras-layout weight file."""
-    h = lib()
-    if h is None:
-        raise RuntimeError("libhdf5 not found (set SMH_LIBHDF5); use the .npz format")
     layers = OrderedDict()
     for name, arr in weights.items():
         layer, wname = split_name(name)
         layers.setdefault(layer, OrderedDict())[wname] = np.ascontiguousarray(arr, dtype=np.float32)
+    write_layers(path, layers, backend, keras_version)
+
+
+def write_layers(path, layers, backend=b"tensorflow", keras_version=b"2.4.0"):
+    """layers: ordered mapping layer name -> ordered mapping Keras weight name ('<layer>/kernel:0', ...) -> array; layers
+    without weights (activations, dropout, ...) carry an empty mapping, as in the files Keras writes."""
+    h = lib()
+    if h is None:
+        raise RuntimeError("libhdf5 not found (set SMH_LIBHDF5); use the .npz format")
     f = _ok(h.H5Fcreate(os.fsencode(path), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), "H5Fcreate " + str(path))
     try:
         lcpl = _ok(h.H5Pcreate(h.P_LINK_CREATE), "H5Pcreate")
@@ -160,6 +166,7 @@ def write_weights(path, weights, backend=b"tensorflow", keras_version=b"2.4.0"):
             g = _ok(h.H5Gcreate2(f, layer.encode(), lcpl, H5P_DEFAULT, H5P_DEFAULT), "H5Gcreate2 " + layer)
             _write_str_attr(h, g, "weight_names", [w.encode() for w in ws])
             for wname, arr in ws.items():
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
                 dims = (hsize_t * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
                 sp = _ok(h.H5Screate_simple(max(arr.ndim, 1), dims, None), "H5Screate_simple")
                 d = _ok(h.H5Dcreate2(g, wname.encode(), h.T_F32LE, sp, lcpl, H5P_DEFAULT, H5P_DEFAULT), "H5Dcreate2 " + wname)

@@ -11,9 +11,11 @@ from ..cnn_models import CnnMTL
 from ..model import B3MTL
 
 
-def get_Lemaire_MTL_model(TR_STEPS, N_MELS=120, n_classes=3, patch_size=68, loss_weights=None, seed=None):
+def get_Lemaire_MTL_model(TR_STEPS, N_MELS=120, n_classes=3, patch_size=68, loss_weights=None, seed=None, tcn_block="2.3"):
+    """tcn_block: which residual block the third-party `tcn.TCN` (unpinned in the reference) builds -- "2.3" (default: the API
+    the reference's positional call at :144 binds under) or "2.8" (two-convolution block, inference only)."""
     model = B3MTL(n_feat=N_MELS, patch_size=patch_size, n_classes=n_classes, TR_STEPS=TR_STEPS,
-                  loss_weights=loss_weights, seed=seed)
+                  loss_weights=loss_weights, seed=seed, tcn_block=tcn_block)
     return model, model.initial_learning_rate
 
 

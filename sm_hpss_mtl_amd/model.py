@@ -32,16 +32,27 @@ def head_spec(n_classes: int):
     return [("S", 1, "sigmoid"), ("M", 1, "sigmoid"), ("R", 2, "linear")]
 
 
-def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_stacks=3, n_dil=8):
-    """Ordered (name, shape, fan_in, fan_out|None) in canonical order; fan_out None -> not glorot."""
+def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_stacks=3, n_dil=8, block_variant=0):
+    """Ordered (name, shape, fan_in, fan_out|None) in canonical order; fan_out None -> not glorot.
+    block_variant 0: the keras-tcn 2.3.x block; 1: the two-convolution block of keras-tcn >= 2.8 (include/smh.h)."""
     Cf, D = nb_filters, patch_size * nb_filters
-    spec = [("tcn/initial_conv/kernel", (1, n_feat, Cf), n_feat, Cf), ("tcn/initial_conv/bias", (Cf,), 0, None)]
+    spec = []
+    if block_variant == 0:
+        spec = [("tcn/initial_conv/kernel", (1, n_feat, Cf), n_feat, Cf), ("tcn/initial_conv/bias", (Cf,), 0, None)]
+    cin = n_feat
     for s in range(nb_stacks):
         for i in range(n_dil):
             p = "tcn/s%d_d%d" % (s, 2 ** i)
-            spec += [(p + "/conv/kernel", (kernel_size, Cf, Cf), kernel_size * Cf, kernel_size * Cf),
-                     (p + "/conv/bias", (Cf,), 0, None),
-                     (p + "/conv1x1/kernel", (1, Cf, Cf), Cf, Cf), (p + "/conv1x1/bias", (Cf,), 0, None)]
+            if block_variant == 0:
+                spec += [(p + "/conv/kernel", (kernel_size, Cf, Cf), kernel_size * Cf, kernel_size * Cf),
+                         (p + "/conv/bias", (Cf,), 0, None),
+                         (p + "/conv1x1/kernel", (1, Cf, Cf), Cf, Cf), (p + "/conv1x1/bias", (Cf,), 0, None)]
+            else:
+                spec += [(p + "/conv0/kernel", (kernel_size, cin, Cf), kernel_size * cin, kernel_size * Cf), (p + "/conv0/bias", (Cf,), 0, None),
+                         (p + "/conv1/kernel", (kernel_size, Cf, Cf), kernel_size * Cf, kernel_size * Cf), (p + "/conv1/bias", (Cf,), 0, None)]
+                if cin != Cf:
+                    spec += [(p + "/matching/kernel", (1, cin, Cf), cin, Cf), (p + "/matching/bias", (Cf,), 0, None)]
+                cin = Cf
     spec += [("3C/kernel", (D, n_classes), D, n_classes), ("3C/bias", (n_classes,), 0, None)]
     for name, odim, _ in head_spec(n_classes):
         spec += [(name + "/dense/kernel", (D, 16), D, 16), (name + "/dense/bias", (16,), 0, None),
@@ -52,7 +63,7 @@ def weight_spec(n_feat, patch_size, n_classes, nb_filters=32, kernel_size=3, nb_
 
 
 def initial_weights(n_feat=240, patch_size=68, n_classes=3, seed=None, nb_filters=32, kernel_size=3, nb_stacks=3,
-                    n_dilations=8):
+                    n_dilations=8, block_variant=0):
     """(dropout_rate, OrderedDict name -> float32 array) of a freshly built model: Keras defaults (glorot_uniform
     kernels, zero biases, BatchNormalization gamma = moving_variance = 1) and the build-time draw of the spatial
     dropout rate (proposed_architectures.py:136).  Host-only (numpy): `B3MTL.__init__` and the generator of
@@ -61,7 +72,7 @@ def initial_weights(n_feat=240, patch_size=68, n_classes=3, seed=None, nb_filter
     dropout_rate = float(rng.uniform(0.05, 0.5))
     weights = OrderedDict()
     for name, shape, fan_in, fan_out in weight_spec(n_feat, patch_size, n_classes, nb_filters, kernel_size, nb_stacks,
-                                                    n_dilations):
+                                                    n_dilations, block_variant):
         if fan_out is not None:
             lim = np.sqrt(6.0 / (fan_in + fan_out))
             weights[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
@@ -74,21 +85,29 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
     """`model` object of get_Lemaire_MTL_model.  Inference runs entirely in libsmh (HIP)."""
 
     def __init__(self, n_feat=240, patch_size=68, n_classes=3, TR_STEPS=1, loss_weights=None, seed=None,
-                 nb_filters=32, kernel_size=3, nb_stacks=3, n_dilations=8):
+                 nb_filters=32, kernel_size=3, nb_stacks=3, n_dilations=8, tcn_block="2.3"):
+        """tcn_block: residual block of the third-party `tcn.TCN` the model was built with -- "2.3" (keras-tcn 2.3.x, what the
+        reference's call binds under; default) or "2.8" (the two-convolution block of later releases; inference only)."""
+        if str(tcn_block) not in ("2.3", "2.8"):
+            raise ValueError("tcn_block must be '2.3' or '2.8', got %r" % (tcn_block,))
+        self.tcn_block = str(tcn_block)
+        self.block_variant = 0 if self.tcn_block == "2.3" else 1
         self.lib = _lib.require_gpu()
         self.n_feat, self.patch_size, self.n_classes = int(n_feat), int(patch_size), int(n_classes)
         self.nb_filters, self.kernel_size, self.nb_stacks, self.n_dilations = nb_filters, kernel_size, nb_stacks, n_dilations
         self.TR_STEPS, self.loss_weights = TR_STEPS, loss_weights
         # proposed_architectures.py:136 draws the (training-only) spatial dropout rate at build time
         self.dropout_rate, self.weights = initial_weights(self.n_feat, self.patch_size, self.n_classes, seed, nb_filters,
-                                                          kernel_size, nb_stacks, n_dilations)
+                                                          kernel_size, nb_stacks, n_dilations, self.block_variant)
         self.initial_learning_rate = 0.002
-        cfg = _lib.ModelCfg(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
+        cfg = _lib.ModelCfg(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations,
+                            self.block_variant)
         h = C.c_void_p()
         _lib.check(self.lib.smh_model_create(C.byref(cfg), C.byref(h)), "smh_model_create")
         self._h = h
         self.out_dim = self.lib.smh_model_out_dim(self._h)
-        self._spec = weight_spec(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations)
+        self._spec = weight_spec(self.n_feat, self.patch_size, self.n_classes, nb_filters, kernel_size, nb_stacks, n_dilations,
+                                 self.block_variant)
         assert self.count_params() == self.lib.smh_model_num_params(self._h)
         self._dirty = True          # host copy newer than the device master
         self._device_newer = False  # device master newer than the host copy (after optimiser steps)
@@ -159,15 +178,19 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         self._pull_weights()
         return save_weights_file(path, self.weights)
 
-    def load_weights(self, path):
+    def load_weights(self, path, arch_json=None):
+        """Weights written by `save_weights` (.h5 / .npz), or an .h5 file written by Keras itself for this architecture:
+        its auto-generated layer names are mapped through the architecture JSON (`arch_json`: path or text; default
+        `<path without .h5>.json`, the file the reference writes next to the weights)."""
         from .persistence import load_weights_file
-        self.set_weights_dict(load_weights_file(path))
+        self.set_weights_dict(load_weights_file(path, arch_json=arch_json))
 
     def to_json(self):
         return json.dumps({"class_name": "B3_MTL", "config": {
             "n_feat": self.n_feat, "patch_size": self.patch_size, "n_classes": self.n_classes,
             "nb_filters": self.nb_filters, "kernel_size": self.kernel_size, "nb_stacks": self.nb_stacks,
-            "n_dilations": self.n_dilations, "dropout_rate": self.dropout_rate, "outputs": self.output_names}})
+            "n_dilations": self.n_dilations, "dropout_rate": self.dropout_rate, "outputs": self.output_names,
+            "tcn_block": self.tcn_block}})
 
     def summary(self, print_fn=print):
         print_fn("Model: B3_MTL (Lemaire et al. TCN + MTL heads), input (None, %d, %d)" % (self.patch_size, self.n_feat))
@@ -217,6 +240,8 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         if not (isinstance(x0p, torch.Tensor) and x0p.is_cuda and x0p.dtype == torch.float32):
             raise TypeError("forward_from_x0 expects a float32 CUDA tensor")
         x0p = x0p.contiguous()
+        if self.block_variant != 0:
+            raise ValueError("the layer-0 fusion exists for the keras-tcn 2.3.x block only")
         if x0p.dim() != 4 or tuple(x0p.shape[1:]) != (2, self.patch_size, 32):
             raise ValueError("expected (N, 2, %d, 32), got %s" % (self.patch_size, tuple(x0p.shape)))
         self._sync_weights()

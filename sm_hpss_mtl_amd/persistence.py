@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import json
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -32,28 +33,146 @@ def save_weights_file(path, weights):
     return p
 
 
-def load_weights_file(path):
-    """-> dict canonical tensor name -> array, from an HDF5 weight file or the .npz form."""
+def load_weights_file(path, arch_json=None):
+    """-> dict canonical tensor name -> array, from an HDF5 weight file or the .npz form.  An HDF5 file written by Keras
+    itself (auto-generated layer names) is mapped onto the canonical names (`keras_layers_to_canonical`), with the help of
+    the architecture JSON the reference saves next to it (`<name>.json`, Proposed_Work_Results.py:372-373) when found."""
     path = str(path)
     if os.path.isfile(path):
         with open(path, "rb") as f:
             magic = f.read(8)
         if magic == b"\x89HDF\r\n\x1a\n":
             layers, _ = h5io.read_weights(path)
-            return {name: arr for ws in layers.values() for name, arr in ws.items()}
+            flat = {name: arr for ws in layers.values() for name, arr in ws.items()}
+            if any(k.startswith("tcn/") or "/dense/kernel" in k for k in flat) or any(k.startswith("conv1/") for k in flat):
+                return flat  # written by save_weights of this package
+            if arch_json is None and os.path.exists(os.path.splitext(path)[0] + ".json"):
+                arch_json = os.path.splitext(path)[0] + ".json"
+            arch = None
+            if arch_json is not None:
+                arch = json.loads(arch_json) if str(arch_json).lstrip().startswith("{") else json.load(open(arch_json))
+            return keras_layers_to_canonical(layers, arch)
     p = path if path.endswith(".npz") else path + ".npz"
     with np.load(p) as z:
         return {k.replace("__", "/"): z[k] for k in z.files}
+
+
+def keras_layers_to_canonical(layers, arch=None):
+    """Weights of a B3_MTL model as Keras wrote them -> canonical tensor names of this package.
+
+    layers: ordered mapping Keras layer name -> ordered mapping weight name -> array (`h5io.read_weights`), e.g.
+    'tcn_initial_conv', 'tcn_dilated_conv_1_tanh_s0', 'conv1d_7', 'dense_3', 'batch_normalization_2', 'S', 'M', 'R', '3C'
+    [recollection of keras-tcn 2.3.x / tf.keras layer naming; the exact names do not matter here].
+    arch: the parsed `model.to_json()` of the Keras model, or None.
+
+    The TCN's Conv1D layers are taken in file order (= creation order = graph order): initial 1x1 conv, then per residual
+    block the dilated conv followed by its 1x1 conv; shapes are checked.  The output layers carry the names the reference
+    gave them ('S', 'M', 'N', 'R', '3C': lib/proposed_architectures.py:52,65,78,150).  Which Dense(16) / BatchNormalization
+    pair feeds which head is read off the architecture JSON (inbound_nodes: out Dense <- Dropout <- Activation <-
+    BatchNormalization <- Dense(16) <- Flatten).  Without the JSON the heads' hidden layers are assigned in creation order
+    (S, M, [N,] R -- the order MTL_modifications builds them in); the dead first 'x_mu' / 'x_smr' blocks (:55-58, :68-71)
+    are not part of the saved graph."""
+    convs, dense16, bns, named = [], [], [], {}
+    for lname, ws in layers.items():
+        arrs = list(ws.values())
+        if not arrs:
+            continue
+        if lname in ("S", "M", "N", "R", "3C"):
+            named[lname] = arrs
+        elif len(arrs) == 2 and arrs[0].ndim == 3:
+            convs.append((lname, arrs))
+        elif len(arrs) == 2 and arrs[0].ndim == 2 and arrs[0].shape[1] == 16:
+            dense16.append((lname, arrs))
+        elif len(arrs) == 4 and all(a.shape == (16,) for a in arrs):
+            bns.append((lname, arrs))
+        else:
+            raise ValueError("keras weight file: layer %r with shapes %s does not belong to a B3_MTL graph" % (lname, [a.shape for a in arrs]))
+    if "3C" not in named or len(convs) < 3 or (len(convs) - 1) % 2:
+        raise ValueError("keras weight file: expected an initial Conv1D, (dilated conv, 1x1 conv) pairs and a '3C' output layer")
+    out = OrderedDict()
+    out["tcn/initial_conv/kernel"], out["tcn/initial_conv/bias"] = convs[0][1]
+    C = convs[0][1][0].shape[2]
+    n_blocks = (len(convs) - 1) // 2
+    n_dil = 8
+    if n_blocks % n_dil:
+        raise ValueError("keras weight file: %d residual blocks is not a multiple of the 8 dilations" % n_blocks)
+    for b in range(n_blocks):
+        (_, (k1, b1)), (_, (k2, b2)) = convs[1 + 2 * b], convs[2 + 2 * b]
+        if k1.shape[1:] != (C, C) or k2.shape != (1, C, C):
+            raise ValueError("keras weight file: block %d has kernels %s / %s" % (b, k1.shape, k2.shape))
+        p = "tcn/s%d_d%d" % (b // n_dil, 2 ** (b % n_dil))
+        out[p + "/conv/kernel"], out[p + "/conv/bias"], out[p + "/conv1x1/kernel"], out[p + "/conv1x1/bias"] = k1, b1, k2, b2
+    out["3C/kernel"], out["3C/bias"] = named["3C"]
+    heads = [h for h in ("S", "M", "N", "R") if h in named]
+    if len(dense16) != len(heads) or len(bns) != len(heads):
+        raise ValueError("keras weight file: %d heads but %d Dense(16) / %d BatchNormalization layers" % (len(heads), len(dense16), len(bns)))
+    feeder = {}
+    if arch is not None:
+        cfg_layers = arch["config"]["layers"]
+        inbound = {}
+        for L in cfg_layers:
+            src = []
+            for node in L.get("inbound_nodes", []):
+                for ref in (node if isinstance(node, list) else []):
+                    if isinstance(ref, list) and ref and isinstance(ref[0], str):
+                        src.append(ref[0])
+            inbound[L["name"]] = src
+        cls = {L["name"]: L["class_name"] for L in cfg_layers}
+        for h in heads:
+            cur, found = h, {}
+            for _ in range(8):  # walk up: Dense(out) <- Dropout <- Activation <- BatchNormalization <- Dense(16)
+                ups = inbound.get(cur, [])
+                if len(ups) != 1:
+                    break
+                cur = ups[0]
+                if cls.get(cur) == "BatchNormalization":
+                    found["bn"] = cur
+                elif cls.get(cur) == "Dense":
+                    found["dense"] = cur
+                    break
+            if "bn" not in found or "dense" not in found:
+                raise ValueError("architecture JSON: cannot trace head %r back to its BatchNormalization / Dense(16)" % h)
+            feeder[h] = (found["dense"], found["bn"])
+    else:
+        for i, h in enumerate(heads):  # creation order
+            feeder[h] = (dense16[i][0], bns[i][0])
+    d16, bnd = dict(dense16), dict(bns)
+    for h in heads:
+        dn, bn = feeder[h]
+        if dn not in d16 or bn not in bnd:
+            raise ValueError("architecture JSON names layers %r / %r that the weight file does not hold" % (dn, bn))
+        out[h + "/dense/kernel"], out[h + "/dense/bias"] = d16[dn]
+        out[h + "/bn/gamma"], out[h + "/bn/beta"], out[h + "/bn/moving_mean"], out[h + "/bn/moving_variance"] = bnd[bn]
+        out[h + "/out/kernel"], out[h + "/out/bias"] = named[h]
+    return out
 
 
 def model_from_json(text, seed=None):
     """Inverse of B3MTL.to_json / CnnMTL.to_json (tensorflow.keras.models.model_from_json at the call site)."""
     d = json.loads(text)
     name, cfg = d.get("class_name"), d.get("config", {})
+    if name in ("Functional", "Model") and isinstance(cfg.get("layers"), list):
+        # an architecture file Keras wrote for the reference's B3_MTL graph (Proposed_Work_Results.py:372-373): read the
+        # constructor arguments off it -- Input (None, patch_size, N_MELS), units of '3C', the SpatialDropout1D rate
+        L = {l["name"]: l for l in cfg["layers"]}
+        inp = next(l for l in cfg["layers"] if l["class_name"] == "InputLayer")
+        shp = inp["config"].get("batch_input_shape") or inp["config"].get("batch_shape")
+        if "3C" not in L or len(shp) != 3:
+            raise ValueError("model_from_json: this Keras architecture is not the B3_MTL graph (TCN input, '3C' output)")
+        n_conv = sum(1 for l in cfg["layers"] if l["class_name"] == "Conv1D")
+        if (n_conv - 1) % 16:
+            raise ValueError("model_from_json: %d Conv1D layers: not 1 + 2 x (stacks x 8 dilations)" % n_conv)
+        from .model import B3MTL
+        m = B3MTL(n_feat=int(shp[2]), patch_size=int(shp[1]), n_classes=int(L["3C"]["config"]["units"]), seed=seed,
+                  nb_stacks=(n_conv - 1) // 16)
+        rates = [l["config"]["rate"] for l in cfg["layers"] if l["class_name"] == "SpatialDropout1D"]
+        if rates:
+            m.dropout_rate = float(rates[0])
+        return m
     if name == "B3_MTL":
         from .model import B3MTL
         m = B3MTL(n_feat=cfg["n_feat"], patch_size=cfg["patch_size"], n_classes=cfg["n_classes"], seed=seed,
-                  **{k: cfg[k] for k in ("nb_filters", "kernel_size", "nb_stacks", "n_dilations") if k in cfg})
+                  **{k: cfg[k] for k in ("nb_filters", "kernel_size", "nb_stacks", "n_dilations", "tcn_block") if k in cfg})
         if "dropout_rate" in cfg:  # drawn at build time by the reference (proposed_architectures.py:136): part of the architecture
             m.dropout_rate = float(cfg["dropout_rate"])
         return m

@@ -229,6 +229,8 @@ class TrainingMixin:
         n = x.shape[0]
         if x.dim() != 3 or x.shape[1] != self.patch_size or x.shape[2] != self.n_feat:
             raise ValueError("expected input (N, %d, %d), got %s" % (self.patch_size, self.n_feat, tuple(x.shape)))
+        if getattr(self, "block_variant", 0) != 0:
+            raise NotImplementedError("training is built for the keras-tcn 2.3.x block (tcn_block='2.3'); the 2.8 block is inference only")
         yt = y if (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() == 2) else self.pack_targets(y)
         if yt.shape[0] != n:
             raise ValueError("%d inputs but %d target rows" % (n, yt.shape[0]))

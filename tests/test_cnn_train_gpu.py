@@ -401,7 +401,9 @@ def test_growing_the_cnn_trainer_keeps_adam_moments_and_step():
         delta = np.abs(res[1][k] - w[k]).max()
         # the two trainers split their reductions differently (partial-sum buffers are sized by the capacity): the gradients
         # differ in the last bits and Adam's first steps are sign descent, so allow 3 % of the distance travelled
-        assert np.abs(res[0][k] - res[1][k]).max() <= 3e-2 * delta + 1e-6, k  # 1e-6: biases in front of BatchNorm (zero gradient, pure rounding)
+        if k.endswith("/dense/bias"):
+            continue  # a bias in front of BatchNorm: analytically zero gradient, Adam turns its rounding noise into +-lr steps
+        assert np.abs(res[0][k] - res[1][k]).max() <= 3e-2 * delta + 1e-6, k
     # a trainer that forgot its state restarts the bias correction at step 1: the third update would be ~lr per weight,
     # visibly different
     m, w = _model(30, 68, seed=13)

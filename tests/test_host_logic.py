@@ -172,3 +172,91 @@ def test_mode_filtering_matches_the_reference_loop():
     for n, w, k in [(200, 11, 2), (500, 50, 2), (64, 5, 3), (30, 501, 2), (7, 3, 2), (300, 2, 4)]:
         X = rng.integers(0, k, n)
         assert np.array_equal(mode_filtering(X, w), ref(X, w)), (n, w, k)
+
+
+def _keras_style_artifacts(w, n_classes, T, F, shuffle_heads=True):
+    """A weight file + architecture JSON laid out the way tf.keras 2.x writes them for the reference's B3_MTL graph
+    (lib/proposed_architectures.py:85-170) [recollection of the format: root attribute layer_names listing EVERY layer,
+    weight_names per layer, datasets at <layer>/<layer>/<weight>:0; Functional config with inbound_nodes].  Hidden layers carry
+    Keras' auto-generated names (conv1d_N, dense_N, batch_normalization_N); the heads' hidden layers are deliberately NOT in
+    S, M, R order in the file, so only the graph can tell which belongs to which output."""
+    from collections import OrderedDict
+    heads = [h for h in ("S", "M", "N", "R") if (h + "/dense/kernel") in w]
+    layers, cfg = OrderedDict(), []
+
+    def add(cls, name, inbound, weights=None, **conf):
+        layers[name] = OrderedDict((name + "/" + k + ":0", v) for k, v in (weights or {}).items())
+        cfg.append({"class_name": cls, "name": name, "config": dict(name=name, **conf), "inbound_nodes": [[[i, 0, 0, {}] for i in inbound]] if inbound else []})
+
+    add("InputLayer", "input_1", [], batch_input_shape=[None, T, F])
+    add("Conv1D", "tcn_initial_conv", ["input_1"], {"kernel": w["tcn/initial_conv/kernel"], "bias": w["tcn/initial_conv/bias"]}, filters=32)
+    prev, n = "tcn_initial_conv", 0
+    for s in range(3):
+        for i in range(8):
+            d, p = 2 ** i, "tcn/s%d_d%d" % (s, 2 ** i)
+            dc = "tcn_dilated_conv_%d_tanh_s%d" % (d, s)
+            add("Conv1D", dc, [prev], {"kernel": w[p + "/conv/kernel"], "bias": w[p + "/conv/bias"]}, filters=32, dilation_rate=[d])
+            add("Activation", "activation_%d" % (2 * n + 1), [dc])
+            add("Lambda", "lambda_%d" % (n + 1), ["activation_%d" % (2 * n + 1)])
+            add("SpatialDropout1D", "tcn_spatial_dropout1d_%d_s%d_0.250000" % (d, s), ["lambda_%d" % (n + 1)], rate=0.25)
+            c1 = "conv1d_%d" % (n + 1)
+            add("Conv1D", c1, [cfg[-1]["name"]], {"kernel": w[p + "/conv1x1/kernel"], "bias": w[p + "/conv1x1/bias"]}, filters=32)
+            add("Add", "add_%d" % (n + 1), [prev, c1])
+            prev, n = "add_%d" % n if False else "add_%d" % (n + 1), n + 1
+    add("Activation", "activation_49", [prev])
+    add("Flatten", "flatten_1", ["activation_49"])
+    # hidden layers of the heads: created S, (dead M block), M, (dead R block), R -> surviving auto-names skip numbers; listed
+    # here in a scrambled order on purpose
+    order = list(reversed(heads)) if shuffle_heads else heads
+    num = {"S": 1, "M": 3, "N": 4, "R": 6}
+    for h in order:
+        add("Dense", "dense_%d" % num[h], ["flatten_1"], {"kernel": w[h + "/dense/kernel"], "bias": w[h + "/dense/bias"]}, units=16)
+    for h in order:
+        add("BatchNormalization", "batch_normalization_%d" % num[h], ["dense_%d" % num[h]],
+            {"gamma": w[h + "/bn/gamma"], "beta": w[h + "/bn/beta"], "moving_mean": w[h + "/bn/moving_mean"], "moving_variance": w[h + "/bn/moving_variance"]})
+        add("Activation", "activation_5%d" % num[h], ["batch_normalization_%d" % num[h]])
+        add("Dropout", "dropout_%d" % num[h], ["activation_5%d" % num[h]], rate=0.4)
+    for h in heads:
+        add("Dense", h, ["dropout_%d" % num[h]], {"kernel": w[h + "/out/kernel"], "bias": w[h + "/out/bias"]}, units=int(w[h + "/out/kernel"].shape[1]))
+    add("Dense", "3C", ["flatten_1"], {"kernel": w["3C/kernel"], "bias": w["3C/bias"]}, units=n_classes)
+    arch = {"class_name": "Functional", "config": {"name": "model_1", "layers": cfg, "input_layers": [["input_1", 0, 0]],
+                                                     "output_layers": [[h, 0, 0] for h in heads + ["3C"]]}}
+    return layers, arch
+
+
+@pytest.mark.parametrize("ncls", [3, 5])
+def test_keras_written_weight_file_is_mapped_through_the_architecture_json(tmp_path, ncls):
+    """`model_from_json(open(architechtureFile).read()); model.load_weights(weightFile)` on artifacts with
+    Keras' own layer names (Proposed_Work_Results.py:370-384).  Host logic only: the mapping and the file format."""
+    import json
+    from collections import OrderedDict
+    from sm_hpss_mtl_amd import h5io, persistence
+    if not h5io.available():
+        pytest.skip("libhdf5 not found on this machine")
+    from oracle import b3_mtl
+    w = OrderedDict((k, np.asarray(v, np.float32)) for k, v in b3_mtl.init_weights(seed=4, n_feat=240, patch_size=68, n_classes=ncls, randomize_bn=True).items())
+    layers, arch = _keras_style_artifacts(w, ncls, 68, 240)
+    wf, af = str(tmp_path / "fold0_model.h5"), str(tmp_path / "fold0_model.json")
+    h5io.write_layers(wf, layers)
+    json.dump(arch, open(af, "w"))
+    read, _ = h5io.read_weights(wf)
+    assert list(read) == list(layers) and read["activation_49"] == {} and "tcn_initial_conv/kernel" in read["tcn_initial_conv"]
+    got = persistence.load_weights_file(wf)  # finds fold0_model.json next to the weights
+    assert list(got) == list(w)              # canonical order
+    for k in w:
+        assert np.array_equal(got[k], w[k]), k
+    # without the JSON the heads' hidden layers are taken in file order: this file scrambles them, so the result must differ
+    os.remove(af)
+    blind = persistence.load_weights_file(wf)
+    assert not np.array_equal(blind["S/dense/kernel"], w["S/dense/kernel"]) and np.array_equal(blind["3C/kernel"], w["3C/kernel"])
+    # a file in creation order maps without the JSON
+    layers2, _ = _keras_style_artifacts(w, ncls, 68, 240, shuffle_heads=False)
+    h5io.write_layers(str(tmp_path / "b.h5"), layers2)
+    plain = persistence.load_weights_file(str(tmp_path / "b.h5"))
+    assert all(np.array_equal(plain[k], w[k]) for k in w)
+    # a foreign file is refused
+    layers3 = OrderedDict(layers)
+    layers3["conv2d_1"] = OrderedDict([("conv2d_1/kernel:0", np.zeros((3, 3, 1, 8), np.float32))])
+    h5io.write_layers(str(tmp_path / "c.h5"), layers3)
+    with pytest.raises(ValueError):
+        persistence.load_weights_file(str(tmp_path / "c.h5"))

@@ -204,7 +204,12 @@ def test_featuregram_fused_vs_oracle(clips4, feat):
         # medians are exact selections of the GPU's own S
         assert np.array_equal(harm[i], ofe.median_time(S[i], 21)) and np.array_equal(perc[i], ofe.median_freq(S[i], 11))
         if feat.startswith("Log"):
-            # dB domain: abs 1e-3 except where the top-dB / amin floors clip (compare clipped-or-equal)
+            # (1) SURVEY 8(d'): abs 1e-3 dB on EVERY bin against the oracle started from the device's own S -- the medians are
+            # then selections of identical values, what remains is the arithmetic of masks / mel / dB
+            ref_s = ofe.featuregram_from_S(S[i], feat, n_mels=120, l_harm=21, l_perc=11)
+            assert np.max(np.abs(fv[i] - ref_s)) <= 1e-3, (feat, float(np.max(np.abs(fv[i] - ref_s))))
+            # (2) end to end from the audio (oracle: numpy's f64 FFT): the device's f32 STFT differs in the last bits, a few
+            # medians then select a neighbouring value and those bins move by up to 2e-2 dB; 98 % of the bins stay within 1e-3
             half = ref.shape[0] // 2
             for a, b in ((fv[i][:half], ref[:half]), (fv[i][half:], ref[half:])):
                 floor = b.max() - 80
@@ -370,14 +375,17 @@ def test_long_clips_take_the_streaming_paths(fe):
     from sm_hpss_mtl_amd.synth import synth_clips
     y = synth_clips(2, seed=21, n_samples=160000)
     res = fe.run(torch.from_numpy(y).cuda(), W=68, shift=34)
+    S = host(fe.stft_mag(torch.from_numpy(y).cuda()))  # the same kernel: the S the fused call worked on
     fv, patches = host(res["fv"]), host(res["patches"])
     nP = len(ofe.patch_starts(998, 68, 34))
     assert fv.shape == (2, 240, 998) and patches.shape == (2 * nP, 68, 240)
     for i in range(2):
+        ref_s = ofe.featuregram_from_S(S[i], "LogMelHarmPercSpec")
+        assert np.max(np.abs(fv[i] - ref_s)) <= 1e-3          # dB, every bin, from the device's own S
         ref = ofe.featuregram(y[i], "LogMelHarmPercSpec")
-        assert np.max(np.abs(fv[i] - ref)) <= 2e-3  # dB
-        refp = ofe.tcn_input(ofe.feature_patches(ref, 68, 34))
-        assert np.max(np.abs(patches[i * nP:(i + 1) * nP] - refp)) <= 2e-3
+        assert np.max(np.abs(fv[i] - ref)) <= 2e-3            # dB, end to end from the audio (STFT-ulp median flips included)
+        refp = ofe.tcn_input(ofe.feature_patches(fv[i], 68, 34))
+        assert np.max(np.abs(patches[i * nP:(i + 1) * nP] - refp)) <= 2e-4  # standardisation + patch gather of the device's fv
     y60 = synth_clips(1, seed=22, n_samples=960000)
     r60 = fe.run(torch.from_numpy(y60).cuda(), W=68, shift=68)
     torch.cuda.synchronize()
@@ -477,6 +485,7 @@ def test_frontend_randomised_lengths_and_feature_names():
         fe_t = Frontend(cfg)
         y = synth_clips(2, seed=100 + trial, n_samples=n)
         res = fe_t.run(dev(y), W=W, shift=shift)
+        S = host(fe_t.stft_mag(dev(y)))  # the same kernel: the S the fused call worked on
         fv, patches = host(res["fv"]), host(res["patches"])
         T = 1 + (n - n_fft) // 160
         rows = 120 if use_mel else n_fft // 2 + 1
@@ -485,7 +494,85 @@ def test_frontend_randomised_lengths_and_feature_names():
             ref = ofe.featuregram(y[i], name, n_fft=n_fft, n_mels=120, l_harm=lh, l_perc=lp)
             tol = 2e-3 if log else 2e-5 * max(1.0, float(np.abs(ref).max()))
             assert np.max(np.abs(fv[i] - ref)) <= tol, (trial, name, n, float(np.max(np.abs(fv[i] - ref))))
+            if log:  # SURVEY 8(d'): abs 1e-3 dB on every bin once the STFT's last bits are taken out of the comparison
+                ref_s = ofe.featuregram_from_S(S[i], name, n_mels=120, l_harm=lh, l_perc=lp)
+                assert np.max(np.abs(fv[i] - ref_s)) <= 1e-3, (trial, name, n, float(np.max(np.abs(fv[i] - ref_s))))
             nP = res["n_patches"]
             refp = ofe.tcn_input(ofe.feature_patches(fv[i], W, shift, name))  # from the GPU's own fv
             assert refp.shape[0] == nP
             np.testing.assert_allclose(patches[i * nP:(i + 1) * nP], refp, atol=2e-4)
+
+
+def test_reload_of_keras_written_artifacts(tmp_path):
+    """Proposed_Work_Results.py:376-384 on files laid out the way Keras writes them (auto-generated layer names, Functional
+    JSON): model_from_json(architecture) -> load_weights(weights) -> predict equals the oracle on the original weights."""
+    import json
+    from collections import OrderedDict
+    from sm_hpss_mtl_amd import h5io
+    from sm_hpss_mtl_amd.lib.proposed_architectures import model_from_json
+    from tests.test_host_logic import _keras_style_artifacts
+    if not h5io.available():
+        pytest.skip("libhdf5 not found on this machine")
+    w = OrderedDict((k, np.asarray(v, np.float32)) for k, v in b3_mtl.init_weights(seed=8, n_feat=240, patch_size=68, n_classes=3, randomize_bn=True).items())
+    layers, arch = _keras_style_artifacts(w, 3, 68, 240)
+    weightFile, architechtureFile = str(tmp_path / "m.h5"), str(tmp_path / "m.json")
+    h5io.write_layers(weightFile, layers)
+    json.dump(arch, open(architechtureFile, "w"))
+    with open(architechtureFile, "r") as f:
+        model = model_from_json(f.read())
+    model.load_weights(weightFile)
+    assert (model.patch_size, model.n_feat, model.n_classes, model.dropout_rate) == (68, 240, 3, 0.25)
+    x = np.random.default_rng(0).standard_normal((5, 68, 240)).astype(np.float32)
+    ref = b3_mtl.forward(x, w)
+    for a, b in zip(model.predict(x), ref):
+        np.testing.assert_allclose(a, b, atol=1e-4)
+
+
+def test_preallocated_outputs_are_validated(fe, clips4):
+    """The C ABI takes raw pointers without sizes: an `out` dict kept from a smaller batch must be refused, not written past."""
+    S = fe.stft_mag(dev(clips4))
+    harm, perc = fe.hpss_median(S)
+    small = fe.features(S[:2], harm[:2], perc[:2], W=68, shift=68)
+    with pytest.raises(ValueError, match="shape"):
+        fe.features(S, harm, perc, W=68, shift=68, out=small)
+    with pytest.raises(ValueError, match="maxkeys"):
+        fe.features(S, harm, perc, W=68, shift=68, out={"maxkeys": torch.empty(2, dtype=torch.int32, device="cuda")})
+    with pytest.raises(ValueError, match="float32|torch.float32"):
+        fe.features(S, harm, perc, out={"fv": torch.empty((4, 240, 98), dtype=torch.float64, device="cuda")})
+    ok = fe.features(S, harm, perc, W=68, shift=68)
+    again = fe.features(S, harm, perc, W=68, shift=68, out=ok)  # the right shapes are reused in place
+    assert again["fv"].data_ptr() == ok["fv"].data_ptr() and again["patches"].data_ptr() == ok["patches"].data_ptr()
+
+
+@pytest.mark.parametrize("ncls,W,N", [(3, 68, 6), (5, 68, 7), (3, 99, 5), (3, 68, 1030), (3, 249, 3)])
+def test_b3mtl_two_conv_block_variant_vs_oracle(ncls, W, N, tmp_path):
+    """smh_model_cfg.block_variant = 1 (the residual block of keras-tcn >= 2.8: two dilated convolutions, relu each, identity
+    / 1x1 'matching' shortcut, relu of the sum; no initial convolution) against oracle.b3_mtl.tcn_forward_v2."""
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model, model_from_json
+    w = b3_mtl.init_weights_v2(seed=9, n_feat=240, patch_size=W, n_classes=ncls, randomize_bn=True)
+    for k in w:  # keep the un-normalised trunk in a sane range (24 blocks without 'norm_relu')
+        if "/conv" in k and k.endswith("kernel"):
+            w[k] = (w[k] * 0.5).astype(np.float32)
+    m, _ = get_Lemaire_MTL_model(10, N_MELS=240, n_classes=ncls, patch_size=W, tcn_block="2.8")
+    assert [n for n, _, _, _ in m._spec] == list(w) and m.count_params() == sum(v.size for v in w.values())
+    m.set_weights_dict(w)
+    x = np.random.default_rng(12).standard_normal((N, W, 240)).astype(np.float32)
+    trunk = torch.empty((N, W, 32), device="cuda")
+    out = host(m.forward_device(dev(x), trunk=trunk))
+    sel = np.r_[0:min(N, 6) // 2 + 1, N - 2:N] if N > 6 else np.arange(N)
+    ref_outs, ref_trunk = b3_mtl.forward(x[sel], w, n_classes=ncls, return_trunk=True)
+    scale = max(1.0, float(np.abs(ref_trunk).max()))
+    np.testing.assert_allclose(host(trunk)[sel], ref_trunk, atol=2e-4 * scale)
+    ref = np.concatenate(ref_outs, axis=1)
+    np.testing.assert_allclose(out[sel], ref, atol=2e-4)
+    assert np.array_equal(out[sel][:, -ncls:].argmax(1), ref[:, -ncls:].argmax(1))
+    if N == 6:
+        m.save_weights(str(tmp_path / "v2.h5"))
+        m2 = model_from_json(m.to_json())
+        assert m2.tcn_block == "2.8"
+        m2.load_weights(str(tmp_path / "v2.h5"))
+        assert np.array_equal(m2.predict(x)[-1], m.predict(x)[-1])
+        with pytest.raises(NotImplementedError):
+            m.train_on_batch(x, {"S": np.zeros((N, 1)), "M": np.zeros((N, 1)), "R": np.zeros((N, 2)), "3C": np.eye(3)[np.zeros(N, int)]})
+        with pytest.raises(ValueError):
+            m.forward_from_x0(torch.zeros((N, 2, W, 32), device="cuda"))
