@@ -59,15 +59,14 @@ struct smh_ctx {
     // bin-walk form of the fused feature kernel (smh_feat.hip): the feature rows are cut into segments of similar
     // bin counts; for every bin of a segment the plan holds how many finished filters to emit first and the weights
     // of the (at most four) pending ones -- {w0, w1, w2, w3, n_emit, -, -, -} per bin, 32 bytes
-    static constexpr int kMaxFeatSegs = 16;
+    static constexpr int kMaxFeatSegs = 8;
     int feat_walk_ok;
     int feat_pend;  // most filters pending at one bin of the walk (1..4)
-    // three segmentations of the same rows: [0] four segments (two-kernel path, 8 waves per clip),
-    // [1] eight segments (single-kernel path, lane = frame: 16 waves per 1 s clip), [2] sixteen segments (single-kernel path,
-    // lane = frame PAIR: 16 waves per 1 s clip, packed f32 arithmetic)
-    int feat_nseg[3];
-    int feat_m0[3][kMaxFeatSegs], feat_m1[3][kMaxFeatSegs], feat_kbeg[3][kMaxFeatSegs], feat_kend[3][kMaxFeatSegs],
-        feat_off[3][kMaxFeatSegs];
+    // two segmentations of the same rows: [0] four segments (two-kernel path, 8 waves per clip), [1] eight segments
+    // (single-kernel paths: features_half_kernel, 8 waves per clip half; features_clip_kernel, 16 waves per clip)
+    int feat_nseg[2];
+    int feat_m0[2][kMaxFeatSegs], feat_m1[2][kMaxFeatSegs], feat_kbeg[2][kMaxFeatSegs], feat_kend[2][kMaxFeatSegs],
+        feat_off[2][kMaxFeatSegs];
     float *d_feat_plan;
     std::vector<float> h_mel_dense;  // (n_mels, K) host copy
 };

@@ -197,9 +197,9 @@ extern "C" int smh_ctx_create(const smh_frontend_cfg *cfg, smh_ctx **out) {
         auto weight = [&](int m, int k) { return c->n_mels > 0 ? mw[moff[m] + (k - st[m])] : 1.0f; };
         bool ok = true;
         c->feat_pend = 1;
-        for (int v = 0; v < 3; ++v) {
-            int NS = v == 0 ? 4 : (v == 1 ? 8 : 16);  // 4 measured best of 3..8 for the two-kernel path at K = 201, T = 98
-            if (const char *ev = getenv(v == 0 ? "SMH_FEAT_SEGS" : (v == 1 ? "SMH_FEAT_SEGS1" : "SMH_FEAT_SEGS2")))
+        for (int v = 0; v < 2; ++v) {
+            int NS = v == 0 ? 4 : 8;  // 4 measured best of 3..8 for the two-kernel path at K = 201, T = 98
+            if (const char *ev = getenv(v == 0 ? "SMH_FEAT_SEGS" : "SMH_FEAT_SEGS1"))
                 NS = std::max(1, std::min(atoi(ev), (int)smh_ctx::kMaxFeatSegs));  // tuning
             int bound[smh_ctx::kMaxFeatSegs + 1];
             bound[0] = 0;

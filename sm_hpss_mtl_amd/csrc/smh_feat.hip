@@ -562,12 +562,13 @@ __global__ void clip_fv_kernel(float *__restrict__ fv, const int *__restrict__ m
 // LDS: image [2*rows][T|1] + 3 floats per row + 32 ints  (98 frames, 240 rows: 98 KB, one workgroup per CU).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-features_clip_kernel(FeatPlan fp, int log_db, int pair, int stop_after /* tuning: bits 0-3 phase probe, bit 4 no pipelining */, const float *__restrict__ S, const float *__restrict__ harmb,
+features_clip_kernel(FeatPlan fp, int log_db, int stop_after /* tuning: phase probe */, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
                      float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
                      float *__restrict__ x0p) {
     extern __shared__ __attribute__((aligned(16))) float img[];  // [R2][ld]
     using f32x4 = __attribute__((ext_vector_type(4))) float;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int b = blockIdx.x;
     const int ld = T | 1, R2 = 2 * rows;
     float *s_mean = img + (size_t)R2 * ld;  // mean hi [R2], 1/scale [R2], mean lo [R2]
@@ -579,126 +580,9 @@ features_clip_kernel(FeatPlan fp, int log_db, int pair, int stop_after /* tuning
     const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
     float mxH = 0.f, mxP = 0.f;  // maxima of the filter sums (sums of non-negative terms)
 
-    // ---- the bin walk, lane = PAIR of frames (even T): every load is 8 bytes, the masks and the filter sums run on packed
-    // f32 instructions (v_pk_mul / v_pk_add / v_pk_fma: two frames per VALU slot).  The soft masks are evaluated as
-    //   H = S h^2 / (h^2 + p^2),  P = S p^2 / (h^2 + p^2)        (one reciprocal per frame)
-    // which is librosa's m / (m + r) with m = (h/Z)^2, r = (p/Z)^2, Z = max(h, p) without the normalisation by Z; where
-    // h^2 + p^2 would leave the normal range (both medians below ~1e-15: digital silence) the wave takes the
-    // normalised form with its split_zeros rule instead (wave-uniform branch, practically never taken).
-    // The image receives the filter sums themselves (magnitudes); the dB conversion waits for the write phase below, where
-    // the VALU idles behind the stores (in the walk the four v_log per emitted pair were a third of the instruction slots).
-    // NP = pending filters per bin: 2 for every Slaney bank whose filters are at least as wide as they are apart (the
-    // reference's 120 mels over 201 bins: a frequency lies in exactly two triangles), 4 in general.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int npair = T >> 1;
-    const int nwp = (npair + 63) >> 6;
-    auto pair_walk = [&](auto np_c, auto pipe_c) {
-        constexpr int NP = decltype(np_c)::value;
-        constexpr bool PIPE = decltype(pipe_c)::value;
-        for (int task = wave; task < fp.nseg * nwp; task += nw) {
-            const int seg = __builtin_amdgcn_readfirstlane(task / nwp);
-            const int tw = task - seg * nwp;
-            const int l = tw * 64 + lane;
-            const bool active = l < npair;
-            const int t0 = 2 * min(l, npair - 1);
-            const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
-            int mcur = fp.m0[seg];
-            const float *plan = fp.plan + fp.off[seg];
-            f32x2 aH[NP], aP[NP];
-#pragma unroll
-            for (int e = 0; e < NP; ++e) aH[e] = f32x2{0.f, 0.f}, aP[e] = f32x2{0.f, 0.f};
-            auto emit_first = [&]() {
-                const f32x2 vH = aH[0], vP = aP[0];
-                mxH = fmaxf(mxH, fmaxf(vH.x, vH.y)), mxP = fmaxf(mxP, fmaxf(vP.x, vP.y));
-                if (active) {
-                    float *oh = img + mcur * ld + t0, *op = img + (rows + mcur) * ld + t0;
-                    oh[0] = vH.x, oh[1] = vH.y;
-                    op[0] = vP.x, op[1] = vP.y;
-                }
-#pragma unroll
-                for (int e = 0; e + 1 < NP; ++e) aH[e] = aH[e + 1], aP[e] = aP[e + 1];
-                aH[NP - 1] = f32x2{0.f, 0.f}, aP[NP - 1] = f32x2{0.f, 0.f};
-                ++mcur;
-            };
-            const float *Sb = S + cb + t0, *Pb = perc + cb + t0;
-            const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
-            // Software pipeline over half-batches of kPB bins: the loads of the next half-batch are in flight while this one is
-            // computed.  (All 16 waves of the only workgroup a CU holds run the same program: with "load a batch, wait,
-            // compute" the CU alternated between a memory burst and a compute burst and the walk took their sum.)
-            constexpr int kPB = 4;
-            struct HalfBatch {
-                f32x2 sv[kPB], pv[kPB], hv[kPB];
-                float4 wq[kPB];
-                int ne[kPB];
-            };
-            auto load = [&](int k0, HalfBatch &hb) {
-#pragma unroll
-                for (int u = 0; u < kPB; ++u) {
-                    const int kk = min(k0 + u, K - 1);
-                    hb.sv[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)kk * T);
-                    hb.pv[u] = *reinterpret_cast<const f32x2 *>(Pb + (size_t)kk * T);
-                    hb.hv[u] = *reinterpret_cast<const f32x2 *>(Hb + (size_t)kk * 16);
-                    const int pi = max(min(k0 + u, kend - 1) - kbeg, 0);
-                    hb.wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
-                    hb.ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
-                }
-            };
-            auto compute = [&](int k0, const HalfBatch &hb) {
-#pragma unroll
-                for (int u = 0; u < kPB; ++u) {
-                    if (k0 + u >= kend) break;
-                    for (int i = 0; i < hb.ne[u]; ++i) emit_first();
-                    const f32x2 h2 = hb.hv[u] * hb.hv[u], p2 = hb.pv[u] * hb.pv[u];
-                    const f32x2 den = h2 + p2;
-                    f32x2 H, P;
-                    constexpr float kDenMin = 7.8886091e-31f;  // 2^-100
-                    if (__builtin_expect(__any(den.x < kDenMin || den.y < kDenMin), 0)) {
-                        float Hx, Px, Hy, Py;
-                        hpss_masks_fast(hb.sv[u].x, hb.hv[u].x, hb.pv[u].x, Hx, Px);
-                        hpss_masks_fast(hb.sv[u].y, hb.hv[u].y, hb.pv[u].y, Hy, Py);
-                        H = f32x2{Hx, Hy}, P = f32x2{Px, Py};
-                    } else {
-                        const f32x2 q = hb.sv[u] * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                        H = h2 * q, P = p2 * q;
-                    }
-                    aH[0] += hb.wq[u].x * H, aP[0] += hb.wq[u].x * P;
-                    aH[1] += hb.wq[u].y * H, aP[1] += hb.wq[u].y * P;
-                    if constexpr (NP > 2) {
-                        aH[2] += hb.wq[u].z * H, aP[2] += hb.wq[u].z * P;
-                        aH[3] += hb.wq[u].w * H, aP[3] += hb.wq[u].w * P;
-                    }
-                }
-            };
-            HalfBatch b0, b1;
-            if constexpr (PIPE) {
-                load(kbeg, b0);
-                for (int k0 = kbeg; k0 < kend; k0 += 2 * kPB) {
-                    load(k0 + kPB, b1);
-                    compute(k0, b0);
-                    load(k0 + 2 * kPB, b0);
-                    compute(k0 + kPB, b1);
-                }
-            } else {
-                for (int k0 = kbeg; k0 < kend; k0 += 2 * kPB) {
-                    load(k0, b0);
-                    load(k0 + kPB, b1);
-                    compute(k0, b0);
-                    compute(k0 + kPB, b1);
-                }
-            }
-            while (mcur < m1) emit_first();
-        }
-    };
-    if (pair) {
-        if (fp.pend <= 2) {
-            if (stop_after & 16) pair_walk(std::integral_constant<int, 2>{}, std::false_type{});
-            else pair_walk(std::integral_constant<int, 2>{}, std::true_type{});
-        } else pair_walk(std::integral_constant<int, 4>{}, std::true_type{});
-    }
-    stop_after &= 15;
     // ---- the bin walk, lane = frame (odd T) ----
     const int nwt = (T + 63) >> 6;
-    for (int task = wave; !pair && task < fp.nseg * nwt; task += nw) {
+    for (int task = wave; task < fp.nseg * nwt; task += nw) {
         const int seg = __builtin_amdgcn_readfirstlane(task / nwt);
         const int tw = task - seg * nwt;
         const int t = tw * 64 + lane;
@@ -914,7 +798,16 @@ __global__ void fill_int_kernel(int *p, int n, int v) {
 // beside the other's arithmetic phases (statistics, layer 0) -- with one workgroup per CU the kernel was the plain sum of
 // its phases.  What it costs: both halves stream S / harm / perc (the second read comes from L2: the two
 // workgroups of a clip sit on the same XCD, 8 dispatch slots apart) and evaluate the mask denominator.
-// Even T only (lane = frame pair, packed f32 arithmetic, see features_clip_kernel); odd T keeps features_clip_kernel.
+// Even T only; odd T keeps features_clip_kernel (lane = frame).
+// The bin walk here runs with lane = PAIR of frames: every load is 8 bytes, the masks and the filter sums use packed f32
+// instructions (v_pk_mul / v_pk_add / v_pk_fma: two frames per VALU slot).  The soft mask is evaluated as
+//   out = S own^2 / (own^2 + other^2)          (own = harm for the H half, perc for the P half; one reciprocal per frame)
+// which is librosa's m / (m + r) with m = (h/Z)^2, r = (p/Z)^2, Z = max(h, p) without the normalisation by Z; where
+// own^2 + other^2 would leave the normal range (both medians below ~1e-15: digital silence) the wave takes the normalised
+// form with its split_zeros rule instead (wave-uniform branch, practically never taken).
+// The image receives the filter sums themselves (magnitudes); the dB conversion waits for the write phase, where the VALU
+// idles behind the stores.  NP = pending filters per bin: 2 for every Slaney bank whose filters are at least as wide as they
+// are apart (the reference's 120 mels over 201 bins: a frequency lies in exactly two triangles), 4 in general.
 // ---------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ void __launch_bounds__(512)
@@ -1196,19 +1089,22 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
     size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
     if (x0p) lds += sizeof(float) * 2 * rows * 32;  // the layer's weights
     if (lds > 158 * 1024) return 0;
-    // even T: lane = frame pair over the 16-segment plan (packed f32 arithmetic); odd T: lane = frame, 8 segments
-    const int pair = (T % 2 == 0 && c->feat_nseg[2] > 0 && !getenv("SMH_FEAT_NOPAIR")) ? 1 : 0;
-    const int v = pair ? 2 : 1;
+    // even T: one workgroup per (clip, half), lane = frame pair (features_half_kernel); odd T: one workgroup per clip, lane = frame
+    const int pair = (T % 2 == 0 && !getenv("SMH_FEAT_NOPAIR")) ? 1 : 0;
     FeatPlan fp;
-    fp.nseg = c->feat_nseg[v], fp.pend = c->feat_pend;
+    fp.nseg = c->feat_nseg[1], fp.pend = c->feat_pend;
     for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
-        fp.m0[i] = c->feat_m0[v][i], fp.m1[i] = c->feat_m1[v][i], fp.kbeg[i] = c->feat_kbeg[v][i],
-        fp.kend[i] = c->feat_kend[v][i], fp.off[i] = c->feat_off[v][i];
+        fp.m0[i] = c->feat_m0[1][i], fp.m1[i] = c->feat_m1[1][i], fp.kbeg[i] = c->feat_kbeg[1][i],
+        fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
     fp.plan = c->d_feat_plan;
     const char *stop_ev = getenv("SMH_FEAT_STOP");  // tuning only
     const int stop = stop_ev ? atoi(stop_ev) : 0;
-    if (pair && !getenv("SMH_FEAT_NOSPLIT")) {
-        // one workgroup per (clip, half): half the LDS, two workgroups per CU (features_half_kernel)
+    if (pair) {
+        // half the LDS per workgroup: two share a CU.  The 8 waves take the 8-segment plan, one segment each: every segment
+        // boundary costs a re-read of the bins its filters straddle (8 segments: 280 bin reads for 201 bins; 16 segments,
+        // two per wave: 340 and 5 % slower).  Tried and dropped: disjoint bin ranges with the straddling filters' partial sums
+        // combined by ds_add_f32 in a zeroed image (every bin read once, but 1.7x slower: LDS float atomics); software
+        // pipelining of the walk's half-batches (slower: the loads already overlap across the two workgroups of a CU).
         size_t ldh = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows) + 64;
         if (x0p) ldh += sizeof(float) * rows * 32;
         const unsigned grid = 16u * (unsigned)((B + 7) / 8);
@@ -1225,7 +1121,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         return rch ? rch : 1;
     }
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, pair, stop, S, harmb, perc, K, T, rows,
+    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, K, T, rows,
                        smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
     int rc = smh::launch_status("features_clip_kernel");
     return rc ? rc : 1;
