@@ -37,6 +37,47 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
     return r;
 }
 
+// An MFMA operand as bf16 "hi" (the rounded value) and, in the SPLIT variant, "lo" = bf16(x - hi): x ~ hi + lo to 16
+// mantissa bits.  product<SPLIT> = hi*hi (+ hi*lo + lo*hi): three bf16 products reproduce the f32 product to ~2^-16
+// relative -- the variant that meets the 2e-2 tolerance of SURVEY 8(d') through 24 normalised blocks; the lo*lo term
+// (2^-18) is dropped.
+struct Op {
+    bf16x8 hi, lo;
+};
+template <bool SPLIT>
+__device__ __forceinline__ Op split_op(f32x4 a, f32x4 b) {
+    Op r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.hi[i] = (__bf16)a[i], r.hi[4 + i] = (__bf16)b[i];
+        if (SPLIT) r.lo[i] = (__bf16)(a[i] - (float)r.hi[i]), r.lo[4 + i] = (__bf16)(b[i] - (float)r.hi[4 + i]);
+    }
+    if (!SPLIT) r.lo = r.hi;  // unused
+    return r;
+}
+template <bool SPLIT>
+__device__ __forceinline__ Op zero_op() {
+    Op r;
+    r.hi = zero_bf16x8(), r.lo = r.hi;
+    return r;
+}
+// packed weights: hi at [idx], lo at [lo_off + idx]
+template <bool SPLIT, typename P>
+__device__ __forceinline__ Op load_op(P pk, size_t idx, size_t lo_off) {
+    Op r;
+    r.hi = pk[idx];
+    r.lo = SPLIT ? pk[lo_off + idx] : r.hi;
+    return r;
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 product(const Op &w, const Op &x, f32x4 c) {
+    if (SPLIT) {
+        c = mfma_bf16(w.lo, x.hi, c);  // small terms first
+        c = mfma_bf16(w.hi, x.lo, c);
+    }
+    return mfma_bf16(w.hi, x.hi, c);
+}
+
 struct PackInfo {
     size_t l0, blk0, blk_stride, heads, total;  // offsets in bf16x8 units (16 bytes)
     int steps0;
@@ -55,16 +96,17 @@ PackInfo pack_info(const smh_model *m) {
 // canonical f32 weights -> bf16 operands, one thread per bf16x8
 __global__ void pack_bf16_kernel(const float *__restrict__ flat, Offsets off, PackInfo pi, int F, int T, int n_blocks,
                                  int n_classes, int n_heads, int NH, bf16x8 *__restrict__ dst) {
+    // every branch below fills vf (the eight f32 weights of this operand); hi goes to dst[idx], lo to dst[total + idx]
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pi.total) return;
     const int lane = (int)(idx & 63), q = lane >> 4, j = lane & 15;
-    bf16x8 v;
+    float vf[8];
     if (idx < pi.blk0) {  // layer 0: [s][mt][lane]
         const int smt = (int)(idx >> 6), s = smt >> 1, mt = smt & 1;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int f = 32 * s + 8 * q + i;
-            v[i] = (__bf16)(f < F ? flat[off.w0_k + (size_t)f * C + 16 * mt + j] : 0.f);
+            vf[i] = f < F ? flat[off.w0_k + (size_t)f * C + 16 * mt + j] : 0.f;
         }
     } else if (idx < pi.heads) {  // blocks: [blk][tap*2 + mt | 6 + mt][lane]
         const size_t r = idx - pi.blk0;
@@ -73,14 +115,14 @@ __global__ void pack_bf16_kernel(const float *__restrict__ flat, Offsets off, Pa
         if (e < 6) {
             const int tap = e >> 1, mt = e & 1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (__bf16)flat[wo + ((size_t)tap * C + 8 * q + i) * C + 16 * mt + j];
+            for (int i = 0; i < 8; ++i) vf[i] = flat[wo + ((size_t)tap * C + 8 * q + i) * C + 16 * mt + j];
         } else {
             const int mt = e - 6;
             const size_t k2 = wo + 3 * C * C + C;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int cin = i < 4 ? 4 * q + i : 16 + 4 * q + (i - 4);
-                v[i] = (__bf16)flat[k2 + (size_t)cin * C + 16 * mt + j];
+                vf[i] = flat[k2 + (size_t)cin * C + 16 * mt + j];
             }
         }
     } else {  // Dense-on-trunk: [mt][t][lane], output o = 16 mt + j, k = t*32 + 8q + i
@@ -96,22 +138,27 @@ __global__ void pack_bf16_kernel(const float *__restrict__ flat, Offsets off, Pa
                 const int h = (o - n_classes) / kHidden, jj = (o - n_classes) % kHidden;
                 w = flat[off.head[h] + k * kHidden + jj];
             }
-            v[i] = (__bf16)w;
+            vf[i] = w;
         }
     }
-    dst[idx] = v;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (__bf16)vf[i], lo[i] = (__bf16)(vf[i] - (float)hi[i]);
+    dst[idx] = hi;
+    dst[pi.total + idx] = lo;
 }
 
 struct BlockWb {
-    bf16x8 wc[3][2], wp[2];
+    Op wc[3][2], wp[2];
     f32x4 b1lo, b1hi, b2lo, b2hi;
 };
-__device__ __forceinline__ void load_block(BlockWb &w, const bf16x8 *__restrict__ pk, const float *__restrict__ flat,
+template <bool SPLIT>
+__device__ __forceinline__ void load_block(BlockWb &w, const bf16x8 *__restrict__ pk, size_t lo_off, const float *__restrict__ flat,
                                            size_t wo, int lane, int q) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) w.wc[e >> 1][e & 1] = pk[e * 64 + lane];
-    w.wp[0] = pk[6 * 64 + lane];
-    w.wp[1] = pk[7 * 64 + lane];
+    for (int e = 0; e < 6; ++e) w.wc[e >> 1][e & 1] = load_op<SPLIT>(pk, (size_t)e * 64 + lane, lo_off);
+    w.wp[0] = load_op<SPLIT>(pk, (size_t)6 * 64 + lane, lo_off);
+    w.wp[1] = load_op<SPLIT>(pk, (size_t)7 * 64 + lane, lo_off);
     const float *b1 = flat + wo + 3 * C * C, *b2 = b1 + C + C * C;
     w.b1lo = *reinterpret_cast<const f32x4 *>(b1 + 4 * q);
     w.b1hi = *reinterpret_cast<const f32x4 *>(b1 + 16 + 4 * q);
@@ -119,6 +166,7 @@ __device__ __forceinline__ void load_block(BlockWb &w, const bf16x8 *__restrict_
     w.b2hi = *reinterpret_cast<const f32x4 *>(b2 + 16 + 4 * q);
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ void run_block(const BlockWb &w, int d, int T, int GR, int units, int wave, int nw, int q,
                                           int j, const float *__restrict__ xin, float *__restrict__ xout) {
     for (int u = wave; u < units; u += nw) {
@@ -132,10 +180,10 @@ __device__ __forceinline__ void run_block(const BlockWb &w, int d, int T, int GR
             const bool ok = (t + off >= 0) && (t + off < T);
             if (tap != 1 && !__any(ok)) continue;
             const float *src = xin + (size_t)(ok ? Rc + off : Rc) * SX + 8 * q;
-            bf16x8 b = to_bf16x8(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
-            if (!ok) b = zero_bf16x8();
-            acc0 = mfma_bf16(w.wc[tap][0], b, acc0);
-            acc1 = mfma_bf16(w.wc[tap][1], b, acc1);
+            Op b = split_op<SPLIT>(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+            if (!ok) b = zero_op<SPLIT>();
+            acc0 = product<SPLIT>(w.wc[tap][0], b, acc0);
+            acc1 = product<SPLIT>(w.wc[tap][1], b, acc1);
         }
         float mx = 0.f;
 #pragma unroll
@@ -149,19 +197,20 @@ __device__ __forceinline__ void run_block(const BlockWb &w, int d, int T, int GR
         const float inv = 1.0f / (mx + kNormEps);
         acc0 *= inv;
         acc1 *= inv;
-        const bf16x8 yb = to_bf16x8(acc0, acc1);  // k' = 4q+r, then 16+4q+r: the order the 1x1 operand was packed in
+        const Op yb = split_op<SPLIT>(acc0, acc1);  // k' = 4q+r, then 16+4q+r: the order the 1x1 operand was packed in
         const float *res = xin + (size_t)Rc * SX + 4 * q;
         f32x4 o0 = *reinterpret_cast<const f32x4 *>(res) + w.b2lo;
         f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16) + w.b2hi;
-        o0 = mfma_bf16(w.wp[0], yb, o0);
-        o1 = mfma_bf16(w.wp[1], yb, o1);
+        o0 = product<SPLIT>(w.wp[0], yb, o0);
+        o1 = product<SPLIT>(w.wp[1], yb, o1);
         float *dst = xout + (size_t)R * SX + 4 * q;
         *reinterpret_cast<f32x4 *>(dst) = o0;
         *reinterpret_cast<f32x4 *>(dst + 16) = o1;
     }
 }
 
-__global__ void __launch_bounds__(512, 2)
+template <bool SPLIT>
+__global__ void __launch_bounds__(512)
 b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__restrict__ X, const float *__restrict__ flat,
                           const bf16x8 *__restrict__ pk, const float *__restrict__ hp, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -178,7 +227,10 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
     {
         bf16x8 *w0s = reinterpret_cast<bf16x8 *>(xb);  // layer-0 A operands staged in the not-yet-used buffer
         const int nW0 = pi.steps0 * 2 * 64;
-        for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = pk[pi.l0 + i];
+        for (int i = threadIdx.x; i < nW0; i += blockDim.x) {
+            w0s[i] = pk[pi.l0 + i];
+            if (SPLIT) w0s[nW0 + i] = pk[pi.total + pi.l0 + i];
+        }
         __syncthreads();
         const float *b0 = flat + off.w0_b;
         const f32x4 bl = *reinterpret_cast<const f32x4 *>(b0 + 4 * q), bh = *reinterpret_cast<const f32x4 *>(b0 + 16 + 4 * q);
@@ -206,9 +258,9 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s >= pi.steps0) break;
-                const bf16x8 b = to_bf16x8(xv[2 * s], xv[2 * s + 1]);
-                c0 = mfma_bf16(w0s[(s * 2 + 0) * 64 + lane], b, c0);
-                c1 = mfma_bf16(w0s[(s * 2 + 1) * 64 + lane], b, c1);
+                const Op b = split_op<SPLIT>(xv[2 * s], xv[2 * s + 1]);
+                c0 = product<SPLIT>(load_op<SPLIT>(w0s, (size_t)(s * 2 + 0) * 64 + lane, (size_t)nW0), b, c0);
+                c1 = product<SPLIT>(load_op<SPLIT>(w0s, (size_t)(s * 2 + 1) * 64 + lane, (size_t)nW0), b, c1);
             }
             float *dst = xa + (size_t)R * SX + 4 * q;
             *reinterpret_cast<f32x4 *>(dst) = c0;
@@ -216,23 +268,35 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
         }
     }
 
-    BlockWb wA, wB;
-    load_block(wA, pk + pi.blk0, flat, off.blk0, lane, q);
     float *xin = xa, *xout = xb;
-    for (int blk = 0; blk < a.n_blocks; blk += 2) {
-        if (blk + 1 < a.n_blocks)
-            load_block(wB, pk + pi.blk0 + (size_t)(blk + 1) * pi.blk_stride, flat, off.blk0 + (size_t)(blk + 1) * off.blk_stride, lane, q);
-        __syncthreads();
-        run_block(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout);
-        if (blk + 1 < a.n_blocks) {
-            if (blk + 2 < a.n_blocks)
-                load_block(wA, pk + pi.blk0 + (size_t)(blk + 2) * pi.blk_stride, flat, off.blk0 + (size_t)(blk + 2) * off.blk_stride, lane, q);
+    if constexpr (SPLIT) {  // one register set (hi + lo: 64 operand registers), loaded at the top of the block
+        BlockWb w;
+        for (int blk = 0; blk < a.n_blocks; ++blk) {
+            load_block<true>(w, pk + pi.blk0 + (size_t)blk * pi.blk_stride, pi.total, flat, off.blk0 + (size_t)blk * off.blk_stride, lane, q);
             __syncthreads();
-            run_block(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin);
-        } else {
+            run_block<true>(w, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout);
             float *tmp = xin;
             xin = xout;
             xout = tmp;
+        }
+    } else {
+        BlockWb wA, wB;
+        load_block<false>(wA, pk + pi.blk0, pi.total, flat, off.blk0, lane, q);
+        for (int blk = 0; blk < a.n_blocks; blk += 2) {
+            if (blk + 1 < a.n_blocks)
+                load_block<false>(wB, pk + pi.blk0 + (size_t)(blk + 1) * pi.blk_stride, pi.total, flat, off.blk0 + (size_t)(blk + 1) * off.blk_stride, lane, q);
+            __syncthreads();
+            run_block<false>(wA, 1 << (blk % a.n_dil), T, GR, units, wave, nw, q, j, xin, xout);
+            if (blk + 1 < a.n_blocks) {
+                if (blk + 2 < a.n_blocks)
+                    load_block<false>(wA, pk + pi.blk0 + (size_t)(blk + 2) * pi.blk_stride, pi.total, flat, off.blk0 + (size_t)(blk + 2) * off.blk_stride, lane, q);
+                __syncthreads();
+                run_block<false>(wB, 1 << ((blk + 1) % a.n_dil), T, GR, units, wave, nw, q, j, xout, xin);
+            } else {
+                float *tmp = xin;
+                xin = xout;
+                xout = tmp;
+            }
         }
     }
     __syncthreads();
@@ -258,10 +322,11 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
             const float *xg = xin + (size_t)(live ? j : 0) * T * SX + 8 * q;
             for (int t = t_lo; t < t_hi; ++t) {
                 const float *xr = xg + (size_t)t * SX;
-                bf16x8 b = to_bf16x8(*reinterpret_cast<const f32x4 *>(xr), *reinterpret_cast<const f32x4 *>(xr + 4));
-                if (!live) b = zero_bf16x8();
-                if (t & 1) accB = mfma_bf16(wa[(size_t)t * 64], b, accB);
-                else accA = mfma_bf16(wa[(size_t)t * 64], b, accA);
+                Op b = split_op<SPLIT>(*reinterpret_cast<const f32x4 *>(xr), *reinterpret_cast<const f32x4 *>(xr + 4));
+                if (!live) b = zero_op<SPLIT>();
+                const Op wv = load_op<SPLIT>(wa, (size_t)t * 64, pi.total);
+                if (t & 1) accB = product<SPLIT>(wv, b, accB);
+                else accA = product<SPLIT>(wv, b, accA);
             }
             accA += accB;
 #pragma unroll
@@ -325,7 +390,7 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
 
 }  // namespace
 
-extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream) {
+extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, float *d_out, int split, void *stream) {
     SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_bf16: null argument");
     SMH_REQUIRE(N >= 0, "smh_model_forward_bf16: N=%d", N);
     SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_bf16: built for block_variant 0 only");
@@ -335,7 +400,7 @@ extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, flo
     hipStream_t st = (hipStream_t)stream;
     const PackInfo pi = pack_info(m);
     const Offsets off = offsets(m);
-    if (!m->d_bf16) SMH_CHECK_HIP(hipMalloc(&m->d_bf16, pi.total * 16));
+    if (!m->d_bf16) SMH_CHECK_HIP(hipMalloc(&m->d_bf16, 2 * pi.total * 16));  // hi operands, then lo operands
     if (m->bf16_version != m->version) {  // weights changed since the operands were built
         hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((pi.total + 255) / 256)), dim3(256), 0, st, m->d_flat, off, pi,
                            m->cfg.n_feat, m->cfg.patch_size, m->n_blocks, m->cfg.n_classes, m->n_heads, m->NH,
@@ -348,8 +413,18 @@ extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, flo
     size_t lds;
     fill_args(m, N, &a, &lds);
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(b3mtl_forward_bf16_kernel, dim3((N + a.G - 1) / a.G), dim3(512), lds, st, a, pi, off, d_x, m->d_flat,
-                       (const bf16x8 *)m->d_bf16, m->d_hp, d_out);
+    if (split) {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(b3mtl_forward_bf16_kernel<true>, dim3((N + a.G - 1) / a.G), dim3(512), lds, st, a, pi, off, d_x, m->d_flat,
+                           (const bf16x8 *)m->d_bf16, m->d_hp, d_out);
+    } else {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(b3mtl_forward_bf16_kernel<false>, dim3((N + a.G - 1) / a.G), dim3(512), lds, st, a, pi, off, d_x, m->d_flat,
+                           (const bf16x8 *)m->d_bf16, m->d_hp, d_out);
+    }
     return smh::launch_status("b3mtl_forward_bf16_kernel");
+}
+
+extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream) {
+    return smh_model_forward_bf16_ex(m, d_x, N, d_out, 1, stream);
 }

@@ -220,15 +220,17 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         N = x.shape[0]
         if out is None:
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x.device)
-        if dtype == "bf16":
+        if dtype in ("bf16", "bf16_plain"):
+            # "bf16": hi + lo split operands, three bf16 products per f32 product (within 2e-2 of f32: BASELINE config 5);
+            # "bf16_plain": operands rounded to one bf16 (faster, 3.5-5e-2 from f32: measurement only)
             if trunk is not None:
                 raise ValueError("the trunk tap is only available on the f32 path")
-            _lib.check(self.lib.smh_model_forward_bf16(
-                self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
+            _lib.check(self.lib.smh_model_forward_bf16_ex(
+                self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()), 1 if dtype == "bf16" else 0,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_bf16")
             return out
         if dtype != "f32":
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+            raise ValueError("dtype must be 'f32', 'bf16' or 'bf16_plain'")
         _lib.check(self.lib.smh_model_forward_f32(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),

@@ -1,5 +1,8 @@
 """Mixed-precision B3_MTL forward (bf16 matrix-core operands, f32 accumulation / residual stream / normalisation):
-BASELINE config 5.  It is NOT the parity path; this file states how far it is from the f32 oracle."""
+BASELINE config 5.  It is NOT the parity path; this file states how far it is from the f32 path and the oracle.
+  dtype="bf16"        hi + lo split operands, three bf16 products per f32 product: inside SURVEY 8(d')'s bf16 tolerance
+                      (abs 2e-2, argmax agreement >= 99.5 %); measured ~1e-3.
+  dtype="bf16_plain"  one bf16 per operand: 3.5-5e-2 through the 24 normalised blocks -- outside; kept for measurement."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 # measured on seeded random weights with perturbed BatchNorm statistics (the hardest case for rounding: 24 blocks of
 # 'divide by the channel maximum'): max |output difference| 2-4e-2, argmax of the 3C head identical on > 99.5 %
-TOL_ABS = 6e-2
+TOL_ABS = 6e-2          # bf16_plain
+TOL_SPLIT = 2e-2        # bf16 (split operands): the SURVEY 8(d') tolerance
 MIN_AGREE = 0.995
 
 
@@ -27,15 +31,16 @@ def test_bf16_forward_close_to_f32(ncls, W, N, seed):
     m, w = _model(ncls, W, seed)
     x = torch.randn((N, W, 240), device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
     ref = m.forward_device(x)                      # f32 path (itself within 1e-4 of the oracle)
-    got = m.forward_device(x, dtype="bf16")
-    torch.cuda.synchronize()
-    assert got.shape == ref.shape and torch.isfinite(got).all()
-    err = float((got - ref).abs().max())
-    agree = float((got[:, -ncls:].argmax(1) == ref[:, -ncls:].argmax(1)).float().mean())
-    print("bf16 vs f32: max abs %.3e, argmax agreement %.4f" % (err, agree))
-    assert err <= TOL_ABS and agree >= MIN_AGREE
-    small = np.concatenate(b3_mtl.forward(x[:8].cpu().numpy(), w, ncls), axis=1)   # and against the numpy oracle
-    assert np.max(np.abs(got[:8].cpu().numpy() - small)) <= TOL_ABS
+    small = np.concatenate(b3_mtl.forward(x[:8].cpu().numpy(), w, ncls), axis=1)   # the numpy oracle
+    for dtype, tol in (("bf16", TOL_SPLIT), ("bf16_plain", TOL_ABS)):
+        got = m.forward_device(x, dtype=dtype)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape and torch.isfinite(got).all()
+        err = float((got - ref).abs().max())
+        agree = float((got[:, -ncls:].argmax(1) == ref[:, -ncls:].argmax(1)).float().mean())
+        print("%s vs f32: max abs %.3e, argmax agreement %.4f" % (dtype, err, agree))
+        assert err <= tol and agree >= MIN_AGREE, (dtype, err, agree)
+        assert np.max(np.abs(got[:8].cpu().numpy() - small)) <= tol
 
 
 def test_bf16_operands_follow_weight_updates():
@@ -47,6 +52,6 @@ def test_bf16_operands_follow_weight_updates():
     b = m.forward_device(x, dtype="bf16")
     ref = m.forward_device(x)
     torch.cuda.synchronize()
-    assert not torch.equal(a, b) and float((b - ref).abs().max()) <= TOL_ABS
+    assert not torch.equal(a, b) and float((b - ref).abs().max()) <= TOL_SPLIT
     with pytest.raises(ValueError):
         m.forward_device(x, dtype="fp8")
