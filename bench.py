@@ -198,7 +198,7 @@ def main():
     def traffic(keys):
         vals = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in keys]
         return None if any(v is None for v in vals) else float(sum(vals))
-    feat_keys = ["features_clip"] if want_lay == 2 else ["hp_feat", "std_patch"]
+    feat_keys = (["features_half"] if hp.T % 2 == 0 else ["features_clip"]) if want_lay == 2 else ["hp_feat", "std_patch"]
     for n, keys in (("stft", ["stft"]), ("median", ["median"]), ("features", feat_keys), ("model", ["model"])):
         kernels[n]["pmc_hbm_bytes_per_launch_at_B1024"] = traffic(keys)
     if pmc.get("model", {}).get("SQ_INSTS_MFMA") and B == 1024 and args.model_dtype == "f32":
@@ -225,7 +225,8 @@ def main():
                 "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
                 "traffic": traffic(["model"]) if (B == 1024 and args.model_dtype == "f32") else None}
     else:
-        kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel", "features": "features_clip_kernel" if want_lay == 2 else "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
+        kn = {"stft": "stft400_kernel", "median": "hpss_median_split_kernel",
+              "features": ("features_half_kernel" if hp.T % 2 == 0 else "features_clip_kernel") if want_lay == 2 else "hp_feat_walk_kernel+std_patch_kernel"}[dominant]
         roof = {"kernel": kn, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dominant]["frac"],
                 "traffic": traffic({"stft": ["stft"], "median": ["median"], "features": feat_keys}[dominant]) if B == 1024 else None}

@@ -109,6 +109,20 @@ struct NoPrefetch {
     __device__ __forceinline__ void slot() const {}
     __device__ __forceinline__ void rest(int) const {}
 };
+// One register set (9+ waves): the CURRENT block's weights are read from the LDS slot behind the first tile's operand reads.
+// LDS returns in order, so the first product waits for its operands and the first weight chunk only; the rest of the
+// 20 ds_read_b128 (180 KB per workgroup and block) arrive while the tile's products run instead of standing between the
+// barrier and the first product.
+struct WeightLoad {
+    BlockW &w;
+    const float *wblk;
+    int lane, q;
+    template <int SLOT>
+    __device__ __forceinline__ void slot() const {
+        if constexpr (SLOT == 0) load_block_lds(w, wblk, lane, q);
+    }
+    __device__ __forceinline__ void rest(int) const {}  // a wave without tiles needs no weights
+};
 struct WeightPrefetch {  // behind the last block the reads still run (they fetch the other slot's stale block, unused)
     BlockW &w;
     const float *wblk;
@@ -131,7 +145,7 @@ struct WeightPrefetch {  // behind the last block the reads still run (they fetc
 // ZR: index of the all-zero row behind the activation rows (padding taps read it instead of masking every operand)
 // prefetch: see WeightPrefetch
 template <bool TRAIN, class PF>
-__device__ __forceinline__ void run_block(const BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
+__device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
                                           const float *__restrict__ xin, float *__restrict__ xout,
                                           const float *__restrict__ drop, int dstride, PF prefetch) {
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
@@ -251,13 +265,28 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         const f32x4 bh = *reinterpret_cast<const f32x4 *>(bias0 + 16 + 4 * q);
         if (a.from_x0) {
             // layer 0 was computed by the feature kernel: sum its two per-half partials, add the bias
-            for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
-                const int R = i >> 3, c4 = (i & 7) * 4;
-                const int g = R / T, t = R - g * T;
-                const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + t) * C + c4);
-                f32x4 v = *reinterpret_cast<const f32x4 *>(p0) + *reinterpret_cast<const f32x4 *>(p0 + (size_t)T * C) +
-                          *reinterpret_cast<const f32x4 *>(bias0 + c4);
-                *reinterpret_cast<f32x4 *>(xa + (size_t)R * SX + c4) = v;
+            // all loads of a thread in flight before the first sum (up to 4 rounds x 2 partials: one HBM latency, not four)
+            constexpr int kX0R = 4;
+            const int n4 = GR * (C / 4);
+            for (int i0 = threadIdx.x; i0 < n4; i0 += kX0R * blockDim.x) {
+                f32x4 pa[kX0R], pb[kX0R];
+#pragma unroll
+                for (int r = 0; r < kX0R; ++r) {
+                    const int i = min(i0 + r * (int)blockDim.x, n4 - 1);
+                    const int R = i >> 3, c4 = (i & 7) * 4;
+                    const int g = R / T, t = R - g * T;
+                    const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + t) * C + c4);
+                    pa[r] = *reinterpret_cast<const f32x4 *>(p0);
+                    pb[r] = *reinterpret_cast<const f32x4 *>(p0 + (size_t)T * C);
+                }
+#pragma unroll
+                for (int r = 0; r < kX0R; ++r) {
+                    const int i = i0 + r * (int)blockDim.x;
+                    if (i < n4) {
+                        const int R = i >> 3, c4 = (i & 7) * 4;
+                        *reinterpret_cast<f32x4 *>(xa + (size_t)R * SX + c4) = pa[r] + pb[r] + *reinterpret_cast<const f32x4 *>(bias0 + c4);
+                    }
+                }
             }
         } else if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kMaxU * nw) {
             f32x4 xr[kMaxU][kFQ4];
@@ -348,7 +377,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     };
     const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
     const int dstride = a.n_blocks * C;
-    auto one_block = [&](int blk, const BlockW &w, auto prefetch) {
+    auto one_block = [&](int blk, BlockW &w, auto prefetch) {
         save_acts(xin, blk);
         run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, ZR, ti, q, xin, xout, drop0 ? drop0 + (size_t)blk * C : nullptr, dstride,
                          prefetch);
@@ -386,14 +415,14 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             if (a.wlds) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of block blk's weights has landed
                 __syncthreads();                                  // xin complete, every wave's share has landed
-                load_block_lds(w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q);
-                // the other slot was read at the top of block blk - 1 and consumed before the barrier above: free to refill
+                // the other slot was read during block blk - 1 and consumed before the barrier above: free to refill
                 if (blk + 1 < a.n_blocks) stage(blk + 1);
+                one_block(blk, w, WeightLoad{w, ws + (size_t)(blk & 1) * kBlockFloats, lane, q});
             } else {  // very long patches: no LDS left for the weight slots, every wave reads the block from L2
                 __syncthreads();
                 load_block_lds(w, Wb + (size_t)blk * kBlockFloats, lane, q);
+                one_block(blk, w, NoPrefetch());
             }
-            one_block(blk, w, NoPrefetch());
         }
     }
     __syncthreads();

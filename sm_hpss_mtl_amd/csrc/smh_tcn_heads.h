@@ -44,7 +44,7 @@ __device__ __forceinline__ void dense_and_heads(const TcnArgs &a, const float *x
                     for (int p = 0; p < kOPL; ++p) acc[g][p] = 0.f;
                 for (int t = t_lo; t < t_hi; ++t) {
                     const float *wrow = WhA + (size_t)t * C * ld + lane;
-#pragma unroll 1
+#pragma unroll 2
                     for (int c8 = 0; c8 < 4; ++c8) {
                         float wv[8][kOPL];
 #pragma unroll

@@ -2,22 +2,23 @@
 # Round profile set: kernel-trace stats of the default bench + PMC traffic passes (FETCH_SIZE, WRITE_SIZE separately).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-R=${1:-r01}
+R=${1:-r02}
 rm -rf gpurun_out/prof/final && mkdir -p gpurun_out/prof/final
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/final/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof/final/bench_trace.log 2>&1; echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/final/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/final/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_write.log 2>&1; echo "write rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d gpurun_out/prof/final/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_sq.log 2>&1; echo "sq rc=$?"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/prof/final/pmc_sq2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_sq2.log 2>&1; echo "sq2 rc=$?"
 python3 - "$R" <<'PY'
 import csv, glob, json, collections, sys
 R = sys.argv[1]
-short = {"stft": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat": "hp_feat", "features_clip_kernel": "features_clip", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
+short = {"stft": "stft", "hpss_median": "median", "preprocess_fused_kernel": "preprocess_signal", "hp_feat": "hp_feat", "features_clip_kernel": "features_clip", "features_half_kernel": "features_half", "std_patch_kernel": "std_patch", "b3mtl_forward_kernel": "model"}
 def key(name):
     for k, v in short.items():
         if k in name: return v
     return None
 out = collections.defaultdict(dict)
-for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None)):
+for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None), ("pmc_sq2", None)):
     fs = glob.glob("gpurun_out/prof/final/%s/*/*_counter_collection.csv" % d)
     if not fs: continue
     agg = collections.defaultdict(list)
