@@ -155,6 +155,10 @@ __device__ __forceinline__ void run_stage(int nb, int R, int j, int Ns, float in
     }
 }
 
+// |re + i im| on the hardware square root (v_sqrt_f32, 1 ulp): the correctly rounded expansion of sqrtf costs ~12 more
+// instructions per bin and the STFT kernels are VALU-bound; the parity bound on |S| is 1e-5 of its maximum
+__device__ __forceinline__ float mag(float re, float im) { return __builtin_amdgcn_sqrtf(re * re + im * im); }
+
 __global__ void __launch_bounds__(kThreads)
 stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__restrict__ window,
                 const float2 *__restrict__ twM, const float2 *__restrict__ tw2M, float *__restrict__ S) {
@@ -204,7 +208,7 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
         const float2 wd = cmul(tw2[k], d);  // X = 0.5*e - 0.5*i*w*d
         const float re = 0.5f * (e.x + wd.y);
         const float im = 0.5f * (e.y - wd.x);
-        Sb[(size_t)k * a.T + f] = __builtin_sqrtf(re * re + im * im);
+        Sb[(size_t)k * a.T + f] = mag(re, im);
     }
 }
 
@@ -268,9 +272,9 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     const float *clip = audio + (size_t)b * n_samples + (size_t)t0 * hop;
 
     // phase 1
-    for (int it = tid; it < nf * 25; it += nthr) {
-        const int f = fdiv(it, 1.0f / 25.0f), n2 = it - f * 25;
-        const float2 *fr = reinterpret_cast<const float2 *>(clip + (size_t)f * hop);
+    const int dq1 = nthr / 25, dr1 = nthr - dq1 * 25;
+    for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf;) {
+        const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(f * hop));
         float2 v[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
@@ -282,6 +286,10 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         zf[0] = v[0];
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmul(v[k1], tw[n2 * k1]);
+        n2 += dr1;
+        const int carry = n2 >= 25 ? 1 : 0;
+        n2 -= 25 * carry;
+        f += dq1 + carry;
     }
     __syncthreads();
     // phase 2: read, barrier, compute, write in place (natural order); 8 * F <= blockDim.x items
@@ -303,11 +311,13 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         }
     }
     __syncthreads();
-    // phase 3: untangle + magnitude, one pair (k, M - k) per item
+    // phase 3: untangle + magnitude, one pair (k, M - k) per item.  Item it = k * nf + f, frames fastest (contiguous stores);
+    // (k, f) advance by (nthr / nf, nthr % nf) with a carry instead of a division per item, and every address is a 32-bit
+    // offset from a uniform base: the item used to spend more instructions on 64-bit index arithmetic than on the butterfly.
     float *Sb = S + (size_t)b * K * T + t0;
-    const float inv_nf = 1.0f / (float)nf;
-    for (int it = tid; it < nf * 101; it += nthr) {
-        const int k = fdiv(it, inv_nf), f = it - k * nf;
+    const int dq = nthr / nf, dr = nthr - dq * nf;
+    int k = tid / nf, f = tid - k * nf;
+    for (; k <= M / 2; ) {
         const float2 *zf = Z + f * kMP400;
         const float2 A = zf[k], Bz = zf[k == 0 ? 0 : M - k];
         // X[k] = (e - i g) / 2 and X[M-k] = conj(e + i g) / 2 with e = A + conj(B), g = tw2[k] (A - conj(B)):
@@ -317,12 +327,16 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         const float2 g = cmul(tw2[k], d);
         {
             const float re = 0.5f * (e.x + g.y), im = 0.5f * (e.y - g.x);
-            Sb[(size_t)k * T + f] = __builtin_sqrtf(re * re + im * im);
+            Sb[(unsigned)(k * T + f)] = mag(re, im);
         }
         if (k != M / 2) {
             const float re = 0.5f * (e.x - g.y), im = 0.5f * (e.y + g.x);
-            Sb[(size_t)(M - k) * T + f] = __builtin_sqrtf(re * re + im * im);
+            Sb[(unsigned)((M - k) * T + f)] = mag(re, im);
         }
+        f += dr;
+        const int carry = f >= nf ? 1 : 0;
+        f -= carry * nf;
+        k += dq + carry;
     }
 }
 
