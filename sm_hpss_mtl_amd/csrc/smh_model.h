@@ -23,6 +23,8 @@ struct TcnArgs {
     int N, T, F, FQ, G, GRP, n_blocks, n_dil, vec_ok;
     int D, NH, n_mt, n_classes, n_heads, out_dim, skip_heads;
     int wlds;     // block weights staged through two LDS slots (0: read from L2 by every wave -- patches too long for the slots)
+    unsigned long long *trace;  // tools only (tools/trace_model.py): per-task timestamps of workgroup 0, or nullptr
+    int tune;     // experiment switches of the skewed schedule (SMH_TCN_TUNE; tools only)
     int from_x0;  // X holds the two per-half partials of layer 0, (N, 2, T, 32) (smh_features_l0_f32), instead of patches
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];

@@ -140,10 +140,91 @@ struct WeightPrefetch {  // behind the last block the reads still run (they fetc
     }
 };
 
-// one residual block for this wave's column tiles
+// One column tile (16 time steps x 32 channels) of one residual block: dilated conv -> relu -> channel-max normalisation ->
+// 1x1 conv + bias + residual, xin rows -> xout row R.  R / t / g: this lane's row, its frame index inside its patch and its
+// patch (TileInfo); I numbers the tile inside the wave's list (prefetch slots).
 // drop: SpatialDropout1D masks of this block for the workgroup's first patch, (n, blk) stride dstride
 // ZR: index of the all-zero row behind the activation rows (padding taps read it instead of masking every operand)
-// prefetch: see WeightPrefetch
+template <bool TRAIN, int I, class PF>
+__device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_taps, int T, int GR, int ZR, int R, int t, int g,
+                                             int q, const float *__restrict__ xin, float *__restrict__ xout,
+                                             const float *__restrict__ drop, int dstride, const PF &prefetch) {
+    const int Rc = min(R, GR - 1);
+    // all LDS operands of the tile up front: 3 taps x 8 channels of this lane's k slice (k index = tap*32 + c; MFMA
+    // step s8 of a tap takes channel c = 8 q + s8 from lane group q, so a lane's eight B operands are contiguous in
+    // its activation row: two ds_read_b128 per tap), then the residual row
+    f32x4 b[3][2];
+    bool any_tap[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int off = (tap - 1) * d;
+        const bool ok = (tap == 1) || (side_taps && (t + off >= 0) && (t + off < T));
+        any_tap[tap] = (tap == 1) || (side_taps && __any(ok));  // wave-uniform: no row of the tile is live through this tap
+        // the reads are issued on every path (a dead tap reads the zero row): with a path-independent number of LDS
+        // operations in flight the compiler can wait for exactly the operands a product needs
+        const float *src = xin + (size_t)(ok ? Rc + off : ZR) * SX + 8 * q;
+        b[tap][0] = *reinterpret_cast<const f32x4 *>(src);
+        b[tap][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+    }
+    const float *res = xin + (size_t)Rc * SX + 4 * q;
+    f32x4 o0 = *reinterpret_cast<const f32x4 *>(res);
+    f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch.template slot<2 * I>();
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        if (!any_tap[tap]) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc0 = mfma4(w.wc[tap * 8 + 4 * h + s4][0], b[tap][h][s4], acc0);
+                acc1 = mfma4(w.wc[tap * 8 + 4 * h + s4][1], b[tap][h][s4], acc1);
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch.template slot<2 * I + 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc0[r] = fmaxf(acc0[r], 0.f);
+        acc1[r] = fmaxf(acc1[r], 0.f);
+        mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+    }
+    mx = quad_max(mx);
+    const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
+    f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (TRAIN) {
+        if (drop) {
+            const float *dp = drop + (size_t)g * dstride + 4 * q;
+            dm0 = *reinterpret_cast<const f32x4 *>(dp);
+            dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
+        }
+    }
+    // 1x1 conv on the normalised activations + bias + residual, all from registers
+    o0 += w.b2lo, o1 += w.b2hi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float y0 = acc0[r] * inv * dm0[r];  // channel 4q + r
+        o0 = mfma4(w.wp[r][0], y0, o0);
+        o1 = mfma4(w.wp[r][1], y0, o1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float y1 = acc1[r] * inv * dm1[r];  // channel 16 + 4q + r
+        o0 = mfma4(w.wp[4 + r][0], y1, o0);
+        o1 = mfma4(w.wp[4 + r][1], y1, o1);
+    }
+    float *dst = xout + (size_t)R * SX + 4 * q;
+    *reinterpret_cast<f32x4 *>(dst) = o0;
+    *reinterpret_cast<f32x4 *>(dst + 16) = o1;
+}
+
+// one residual block for this wave's column tiles (barrier-per-block schedule); prefetch: see WeightPrefetch
 template <bool TRAIN, class PF>
 __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
                                           const float *__restrict__ xin, float *__restrict__ xout,
@@ -151,81 +232,7 @@ __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int Z
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
     auto tile = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int R = ti.R[i];
-        const int Rc = min(R, GR - 1);
-        const int t = ti.t[i];
-        // all LDS operands of the tile up front: 3 taps x 8 channels of this lane's k slice (k index = tap*32 + c; MFMA
-        // step s8 of a tap takes channel c = 8 q + s8 from lane group q, so a lane's eight B operands are contiguous in
-        // its activation row: two ds_read_b128 per tap), then the residual row
-        f32x4 b[3][2];
-        bool any_tap[3];
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            const int off = (tap - 1) * d;
-            const bool ok = (tap == 1) || (side_taps && (t + off >= 0) && (t + off < T));
-            any_tap[tap] = (tap == 1) || (side_taps && __any(ok));  // wave-uniform: no row of the tile is live through this tap
-            // the reads are issued on every path (a dead tap reads the zero row): with a path-independent number of LDS
-            // operations in flight the compiler can wait for exactly the operands a product needs
-            const float *src = xin + (size_t)(ok ? Rc + off : ZR) * SX + 8 * q;
-            b[tap][0] = *reinterpret_cast<const f32x4 *>(src);
-            b[tap][1] = *reinterpret_cast<const f32x4 *>(src + 4);
-        }
-        const float *res = xin + (size_t)Rc * SX + 4 * q;
-        f32x4 o0 = *reinterpret_cast<const f32x4 *>(res);
-        f32x4 o1 = *reinterpret_cast<const f32x4 *>(res + 16);
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch.template slot<2 * i>();
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            if (!any_tap[tap]) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    acc0 = mfma4(w.wc[tap * 8 + 4 * h + s4][0], b[tap][h][s4], acc0);
-                    acc1 = mfma4(w.wc[tap * 8 + 4 * h + s4][1], b[tap][h][s4], acc1);
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch.template slot<2 * i + 1>();
-        __builtin_amdgcn_sched_barrier(0);
-        // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
-        float mx = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc0[r] = fmaxf(acc0[r], 0.f);
-            acc1[r] = fmaxf(acc1[r], 0.f);
-            mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
-        }
-        mx = quad_max(mx);
-        const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
-        f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (TRAIN) {
-            if (drop) {
-                const float *dp = drop + (size_t)ti.g[i] * dstride + 4 * q;
-                dm0 = *reinterpret_cast<const f32x4 *>(dp);
-                dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
-            }
-        }
-        // 1x1 conv on the normalised activations + bias + residual, all from registers
-        o0 += w.b2lo, o1 += w.b2hi;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float y0 = acc0[r] * inv * dm0[r];  // channel 4q + r
-            o0 = mfma4(w.wp[r][0], y0, o0);
-            o1 = mfma4(w.wp[r][1], y0, o1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float y1 = acc1[r] * inv * dm1[r];  // channel 16 + 4q + r
-            o0 = mfma4(w.wp[4 + r][0], y1, o0);
-            o1 = mfma4(w.wp[4 + r][1], y1, o1);
-        }
-        float *dst = xout + (size_t)R * SX + 4 * q;
-        *reinterpret_cast<f32x4 *>(dst) = o0;
-        *reinterpret_cast<f32x4 *>(dst + 16) = o1;
+        tile_compute<TRAIN, i>(w, d, side_taps, T, GR, ZR, ti.R[i], ti.t[i], ti.g[i], q, xin, xout, drop, dstride, prefetch);
     };
     static_assert(kMaxTiles == 4, "tile list below");
     if (ti.n > 0) tile(std::integral_constant<int, 0>{});  // wave-uniform
@@ -235,13 +242,22 @@ __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int Z
     prefetch.rest(ti.n);
 }
 
-template <bool TRAIN, bool PREFETCH>
-__global__ void __launch_bounds__(PREFETCH ? 512 : 768)
+// MODE: how the 24 residual blocks are scheduled over the waves (launch_forward chooses)
+constexpr int kOneSet = 0;   // barrier per block, one weight register set read from the LDS slot at the top of the block (9..12 waves)
+constexpr int kPrefetch = 1; // barrier per block, two register sets (8 waves)
+constexpr int kSkew = 2;     // no barrier: (block, tile) tasks dealt round-robin to 8 waves, tile-level completion flags (inference)
+constexpr int kSkewSpinLimit = 1 << 22;  // polls before a wave gives up on a dependency (never reached; the grid must drain)
+
+// TRACE: tools/trace_model.py only -- s_memtime / s_memrealtime stamps into a.trace; every stamp compiles out otherwise
+template <bool TRAIN, int MODE, bool TRACE = false>
+__global__ void __launch_bounds__(MODE == kOneSet ? 768 : 512)
 b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
                      const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
                      float *__restrict__ out, TrainIO tio) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    // (the wave index through readfirstlane: the compiler then keeps everything derived from it -- the task list of the
+    // skewed schedule -- in scalar registers and branches on it without exec masks)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int q = lane >> 4, j = lane & 15;
     const int n0 = blockIdx.x * a.G;
     const int g_here = min(a.G, a.N - n0);
@@ -250,6 +266,8 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     const int units = (GR + 15) >> 4;
     const int ZR = a.GRP;  // all-zero row behind the GRP activation rows of each buffer (padding taps of the dilated conv)
     float *xa = lds, *xb = lds + (size_t)(a.GRP + 1) * SX;
+    const bool tracing = TRACE && a.trace != nullptr;
+    if (tracing && blockIdx.x < 256 && threadIdx.x == 0) a.trace[4 * 3000 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
     // ---- initial Conv1D(32, 1): K order f = q*FQ + s so that every lane streams a contiguous run ----
     // Layer 0 is an HBM stream (261 KB of X per workgroup): every lane issues ALL loads of its column
@@ -385,7 +403,231 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         xin = xout;
         xout = tmp;
     };
-    if (a.wlds && PREFETCH) {
+    if (MODE != kSkew && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+        a.trace[4 * (2000 + blockIdx.x)] = __builtin_amdgcn_s_memtime();
+        a.trace[4 * (2000 + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if constexpr (MODE == kSkew) {
+        // Skewed schedule.  Task n = (block n / units, tile n % units) belongs to wave n % 8, i.e. SIMD n % 4: every SIMD gets a
+        // quarter of the block x tile grid (17 tiles per block are 5-4-4-4 under a barrier per block, 4.25 each here).  A task
+        // starts when the tiles it touches have finished the previous block -- done[x] counts the blocks tile x has completed:
+        //   read-after-write   rows +-d(block) of buffer block % 2, written by the previous block's tasks,
+        //   write-after-read   its output row replaces x(block - 1), which the previous block's tasks read at +-d(block - 1).
+        // Every dependency is a lower-numbered task, every wave runs its tasks in rising order and a wave never waits while
+        // it holds an unpublished flag, so the lowest unfinished task can always run: no deadlock.
+        // Weights: each wave reads block b + 1 from L2 into its second register set while it works on block b (nothing
+        // shared, nothing to synchronise).
+        // The synchronisation is taken off the critical path of a task (it cost 18 % of the loop when every task polled,
+        // read its operands, computed, drained its stores and set its flag in sequence):
+        //   * the flag of task k is published inside task k + 1 of the wave, behind its first tap's products -- LDS returns
+        //     in order, so by then the rows of task k have long landed and the drain is free;
+        //   * the flags task k + 1 depends on are sampled there too and judged behind the dilated-conv products of task k
+        //     + 1..., i.e. one task ahead: if they stand, the operands of the NEXT task are read into the registers the
+        //     current one has just finished with, under its 1x1-conv products.  Only when they do not stand does the wave
+        //     publish, poll and read in sequence after the task.
+        // (an LDS-typed pointer: a generic volatile access would be a flat load that waits for the weight loads in flight)
+        typedef __attribute__((address_space(3))) volatile int lds_vint;
+        lds_vint *done = (lds_vint *)(ws);  // [0..31] per tile, [63] = a wave gave up waiting
+        if (threadIdx.x < 64) done[threadIdx.x] = threadIdx.x == 62 ? nw : 0;  // [62]: the task counter
+        BlockW w0, w1;
+        load_block_lds(w0, Wb, lane, q);
+        __syncthreads();  // x0, zero rows, flags
+        if (tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+            a.trace[4 * (2000 + blockIdx.x)] = __builtin_amdgcn_s_memtime();
+            a.trace[4 * (2000 + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        const int n_tasks = a.n_blocks * units;
+        // Per-task arithmetic is kept short on purpose: a wave issues about one instruction per four cycles, so a hundred
+        // instructions of index arithmetic per task are as long as sixteen products.  Divisions by multiplication:
+        //   x / v == (x * ceil(2^16 / v)) >> 16 for x < 2048, v <= 32;   x / T == umulhi(x, ceil(2^32 / T)) for x, T < 2^16
+        const int m_units = (65536 + units - 1) / units, m_dil = (65536 + a.n_dil - 1) / a.n_dil;
+        const unsigned m_T = (unsigned)(((1ull << 32) + (unsigned)T - 1) / (unsigned)T);
+        const unsigned all_tiles = units >= 32 ? ~0u : (1u << units) - 1;
+        const int xb_off = (a.GRP + 1) * SX, zrow = ZR * SX + 8 * q;
+        struct Ops {  // LDS operands of one task: the three taps' k slices, the residual row, which side taps are live
+            f32x4 b[3][2], r0, r1;
+            bool live0, live2;
+        };
+        auto dil = [&](int blk) { return 1 << (blk - ((blk * m_dil) >> 16) * a.n_dil); };
+        // (every index below is a multiple of four floats; said explicitly so that the reads stay ds_read_b128)
+        auto ld4 = [&](int i) { return *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(lds + i, 16)); };
+        auto issue_ops = [&](Ops &o, int blk, int u) {
+            const int d = dil(blk);
+            const int base = 16 * u, R = base + j;
+            int t = base - T * (int)__umulhi((unsigned)base, m_T) + j;  // frame index of row R inside its patch
+            if (T >= 16) {
+                t -= t >= T ? T : 0;
+            } else {
+                while (__any(t >= T)) t -= t >= T ? T : 0;
+            }
+            const bool past = R >= GR;  // rows behind the last patch repeat its last row (frame T - 1)
+            const int Rc = past ? GR - 1 : R;
+            t = past ? T - 1 : t;
+            const bool ok0 = t >= d, ok2 = t < T - d;  // a dilation >= T leaves both side taps in the zero padding
+            o.live0 = __any(ok0), o.live2 = __any(ok2);
+            const int i1 = __mul24(Rc, SX) + ((blk & 1) ? xb_off : 0) + 8 * q;
+            const int zr = zrow + ((blk & 1) ? xb_off : 0);
+            const int i0 = ok0 ? i1 - d * SX : zr, i2 = ok2 ? i1 + d * SX : zr;
+            o.b[0][0] = ld4(i0), o.b[0][1] = ld4(i0 + 4);
+            o.b[1][0] = ld4(i1), o.b[1][1] = ld4(i1 + 4);
+            o.b[2][0] = ld4(i2), o.b[2][1] = ld4(i2 + 4);
+            const int ir = i1 - 4 * q;
+            o.r0 = ld4(ir), o.r1 = ld4(ir + 16);
+        };
+        // the tiles whose flags task (blk, u) needs, as a bit mask (units <= 32): itself and the tiles its rows +-d(blk),
+        // +-d(blk - 1) fall into -- for an offset d those are the tiles floor(d / 16) and ceil(d / 16) away
+        auto dep_mask = [&](int blk, int u) {
+            const unsigned m = 1u << u;
+            auto reach = [&](int d) {
+                const int lo = d >> 4, hi = (d + 15) >> 4;
+                unsigned r = 0;
+                if (lo < 32) r |= (m << lo) | (m >> lo);
+                if (hi < 32) r |= (m << hi) | (m >> hi);
+                return r;
+            };
+            return (m | reach(dil(blk)) | reach(dil(blk > 0 ? blk - 1 : 0))) & all_tiles;
+        };
+        auto stands = [&](int have, int blk, unsigned mask) {  // every tile of the mask has finished block blk - 1
+            const unsigned ok = (unsigned)__ballot(have >= blk);
+            return (ok & mask) == mask;
+        };
+        auto wait_for = [&](int blk, int u) {
+            const unsigned mask = dep_mask(blk, u);
+            for (int spins = 0;; ++spins) {
+                const int have = done[lane];
+                if (stands(have, blk, mask)) break;
+                if (__any(lane == 63 && have != 0)) break;
+                if (spins > kSkewSpinLimit) {
+                    if (lane == 0) done[63] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        };
+        // the task counter (done[62], starts at the number of waves: wave w begins with task w).  A wave takes its next task
+        // late -- behind the dilated-conv products of the current one -- so that at most the 8 running tasks and a few taken
+        // ones are unfinished at any time: the tiles a taken task depends on lie 15..19 tasks back and have long finished.
+        int n = wave, blk = (n * m_units) >> 16, u = n - blk * units;  // this wave's current task
+        int pend_u = -1, pend_v = 0;                                   // a finished task whose flag is not published yet
+        Ops cur;
+        bool have_cur = n < n_tasks;
+        if (have_cur) {
+            if (blk > 0) wait_for(blk, u);  // fewer tiles than waves: a wave's first task may sit in a later block
+            issue_ops(cur, blk, u);
+        }
+        auto publish = [&]() {
+            if (pend_u >= 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the finished task's rows are in LDS before its flag moves
+                if (lane == 0) done[pend_u] = pend_v;
+                pend_u = -1;
+            }
+        };
+        auto tasks = [&](int blk0, const BlockW &w) {
+            while (have_cur && blk == blk0) {
+                const int dsti = __mul24(16 * u + j, SX) + ((blk & 1) ? 0 : xb_off) + 4 * q;  // this lane's output row
+                const bool stamp = tracing && (a.tune & 128) && blockIdx.x == 0;
+                unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+                if (stamp) st[0] = __builtin_amdgcn_s_memtime();
+                f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
+                auto half_tap = [&](int tp, int h) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        acc0 = mfma4(w.wc[tp * 8 + 4 * h + s4][0], cur.b[tp][h][s4], acc0);
+                        acc1 = mfma4(w.wc[tp * 8 + 4 * h + s4][1], cur.b[tp][h][s4], acc1);
+                    }
+                };
+                half_tap(1, 0);
+                publish();  // behind the first products: the previous task's flag
+                if (stamp) st[1] = __builtin_amdgcn_s_memtime();
+                half_tap(1, 1);
+                if (cur.live0) half_tap(0, 0), half_tap(0, 1);
+                if (cur.live2) half_tap(2, 0), half_tap(2, 1);
+                // take the next task and sample the flags; both are judged behind the epilogue
+                if (stamp) st[2] = __builtin_amdgcn_s_memtime();
+                int taken = 0;
+                if (lane == 0) taken = __hip_atomic_fetch_add((int *)(done + 62), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int have = done[lane];
+                // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc0[r] = fmaxf(acc0[r], 0.f);
+                    acc1[r] = fmaxf(acc1[r], 0.f);
+                    mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+                }
+                mx = quad_max(mx);
+                const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
+                f32x4 o0 = cur.r0 + w.b2lo, o1 = cur.r1 + w.b2hi;
+                asm volatile("" : "+v"(o0), "+v"(o1));  // the sums now: the residual registers are about to be reloaded
+                const int nn = __builtin_amdgcn_readfirstlane(taken);
+                if (stamp) st[3] = __builtin_amdgcn_s_memtime();
+                const int nblk = (nn * m_units) >> 16, nu = nn - nblk * units;
+                const bool have_next = nn < n_tasks;
+                // the operand registers are free: read the next task's operands under the 1x1-conv products, if its tiles stand
+                bool fetched = false;
+                if (have_next) {
+                    if (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu))) {
+                        asm volatile("" ::: "memory");
+                        issue_ops(cur, nblk, nu);
+                        fetched = true;
+                    }
+                }
+                if (stamp) st[4] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = acc0[r] * inv;  // channel 4q + r
+                    o0 = mfma4(w.wp[r][0], y0, o0);
+                    o1 = mfma4(w.wp[r][1], y0, o1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y1 = acc1[r] * inv;  // channel 16 + 4q + r
+                    o0 = mfma4(w.wp[4 + r][0], y1, o0);
+                    o1 = mfma4(w.wp[4 + r][1], y1, o1);
+                }
+                *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti, 16)) = o0;
+                *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti + 16, 16)) = o1;
+                pend_u = u, pend_v = blk + 1;
+                if (stamp) {
+                    st[5] = __builtin_amdgcn_s_memtime();
+                    if (lane == 0) {
+                        unsigned long long *r = a.trace + 8 * (size_t)n;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) r[i] = st[i];
+                        r[6] = wave, r[7] = fetched;
+                    }
+                }
+                if (have_next && !fetched) {  // a dependency was still running: publish, wait, read -- in sequence
+                    if (tracing && (a.tune & 2) && lane == 0) atomicAdd(a.trace + 4 * 3900, 1ull);
+                    publish();
+                    wait_for(nblk, nu);
+                    issue_ops(cur, nblk, nu);
+                }
+                have_cur = have_next;
+                n = nn, blk = nblk, u = nu;
+            }
+        };
+        // the weight loads are unconditional (past the last block: the last block again) so that the number of loads in flight
+        // behind a register set is the same on every path -- the compiler then waits for exactly that set (vmcnt(20 + x))
+        // instead of for the youngest loads of the shortest path, i.e. for the prefetch it has just issued
+        const int last = a.n_blocks - 1;
+        for (int b0 = 0; b0 < a.n_blocks; b0 += 2) {
+            load_block_lds(w1, Wb + (size_t)min(b0 + 1, last) * kBlockFloats, lane, q);
+            tasks(b0, w0);
+            if (b0 + 1 >= a.n_blocks) break;
+            load_block_lds(w0, Wb + (size_t)min(b0 + 2, last) * kBlockFloats, lane, q);
+            tasks(b0 + 1, w1);
+        }
+        publish();
+        xin = (a.n_blocks & 1) ? xb : xa;
+        xout = (a.n_blocks & 1) ? xa : xb;
+        if (tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+            a.trace[4 * (2000 + blockIdx.x) + 2] = __builtin_amdgcn_s_memtime();
+            a.trace[4 * (2000 + blockIdx.x) + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+    } else if (a.wlds && MODE == kPrefetch) {
         // Two register sets: while block b runs from one, the weights of block b + 1 travel LDS -> registers into the other
         // (the 20 ds_read_b128 per wave of a block -- 150 KB of LDS reads per workgroup -- no longer stand between the
         // barrier and the first product).  LDS slot (b & 1) is refilled by LDS-DMA with block b + 2 as soon as every wave
@@ -425,6 +667,10 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             }
         }
     }
+    if (MODE != kSkew && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+        a.trace[4 * (2000 + blockIdx.x) + 2] = __builtin_amdgcn_s_memtime();
+        a.trace[4 * (2000 + blockIdx.x) + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     __syncthreads();
     save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
     if constexpr (TRAIN) __syncthreads();
@@ -439,7 +685,14 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     }
     __syncthreads();
 
+    bool gave_up = false;
+    if constexpr (MODE == kSkew) gave_up = ((__attribute__((address_space(3))) volatile int *)(ws))[63] != 0;  // the heads do not touch ws
     dense_and_heads<TRAIN>(a, xin, xout, WhA, hp, out, tio, n0, g_here);
+    if (tracing && blockIdx.x < 256 && threadIdx.x == 0) a.trace[4 * 3000 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (gave_up) {  // a dependency never arrived: the outputs are not results
+        __syncthreads();
+        for (int i = threadIdx.x; i < g_here * a.out_dim; i += blockDim.x) out[(size_t)n0 * a.out_dim + i] = __builtin_nanf("");
+    }
 }
 
 // gather kernel: packed[i] = map[i] ? flat[map[i] - 1] : 0
@@ -536,6 +789,26 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
 
 }  // namespace
 
+// tools/trace_model.py: timestamps (s_memtime) of every (block, tile) task of workgroup 0 under the skewed schedule
+static unsigned long long *g_trace = nullptr;
+static unsigned g_trace_launches = 0;
+constexpr size_t kTraceWords = 4 * 4096;
+extern "C" int smh_internal_tcn_trace(int enable, unsigned long long *host, size_t words) {
+    if (enable && !g_trace) {
+        if (hipMalloc((void **)&g_trace, 2 * kTraceWords * sizeof(unsigned long long)) != hipSuccess) return -1;
+        (void)hipMemset(g_trace, 0, 2 * kTraceWords * sizeof(unsigned long long));
+    }
+    if (host && g_trace) {
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(host, g_trace, std::min(words, 2 * kTraceWords) * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    if (!enable && g_trace) {
+        (void)hipFree(g_trace);
+        g_trace = nullptr;
+    }
+    return 0;
+}
+
 namespace smh_tcn {
 
 Offsets offsets(const smh_model *m) {
@@ -569,6 +842,8 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     a.N = N, a.T = T, a.F = m->cfg.n_feat, a.FQ = m->FQ, a.n_blocks = m->n_blocks, a.n_dil = m->cfg.n_dilations;
     a.vec_ok = (a.F % 4 == 0) && (a.FQ % 4 == 0) && (a.FQ * 4 == a.F);
     a.skip_heads = 0;
+    a.tune = 0;
+    a.trace = nullptr;
     a.from_x0 = 0;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
@@ -605,6 +880,8 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     a.from_x0 = from_x0;
     if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
     a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
+    if (const char *ev = getenv("SMH_TCN_TUNE")) a.tune = atoi(ev);
+    a.trace = g_trace ? g_trace + (g_trace_launches++ & 1) * kTraceWords : nullptr;  // consecutive launches alternate halves
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
     // waves per workgroup: the block time is (column tiles of the busiest wave) x (time per tile) plus a fixed part, so
     // take the fewest waves in 8..12 that minimise ceil(tiles / waves): 17 tiles (4 patches of 68 frames) -> 9 waves,
@@ -614,26 +891,37 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     for (int w = 9; w <= 12; ++w)
         if ((units + w - 1) / w < (units + nwaves - 1) / nwaves) nwaves = w;
     if (const char *ev = getenv("SMH_TCN_WAVES")) nwaves = std::max(4, std::min(12, atoi(ev)));  // tuning only
-    const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
     // 8 waves (two per SIMD, 256 VGPRs each): two weight register sets, the next block's weights are read behind this
     // block's products.  More waves (170 VGPRs): one set, read at the top of the block.
     bool prefetch = nwaves <= 8 && a.wlds;
     if (const char *ev = getenv("SMH_TCN_PREFETCH")) prefetch = prefetch && atoi(ev) != 0;  // tuning only
+    // inference: the skewed task schedule (8 waves, flags instead of barriers) whenever its tables fit
+    bool skew = !tio && a.wlds && units <= 32 && units >= 1;
+    if (const char *ev = getenv("SMH_TCN_SKEW")) skew = skew && atoi(ev) != 0;  // tuning only
+    if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
+    if (skew) nwaves = std::min(nwaves, 8);
+    const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
     TrainIO io{nullptr, nullptr, nullptr};
     if (tio) io = *tio;
-#define SMH_LAUNCH_FWD(TR, PF)                                                                                          \
+#define SMH_LAUNCH_FWD(TR, MD, TC)                                                                                      \
     do {                                                                                                                \
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<TR, PF>,                                  \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_kernel<TR, MD, TC>,                              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((b3mtl_forward_kernel<TR, PF>), grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb, m->d_WhA,   \
-                           m->d_hp, d_trunk, d_out, io);                                                               \
+        hipLaunchKernelGGL((b3mtl_forward_kernel<TR, MD, TC>), grid, block, lds, st, a, d_x, m->d_W0, m->d_Wb,         \
+                           m->d_WhA, m->d_hp, d_trunk, d_out, io);                                                     \
     } while (0)
     if (tio) {
-        if (prefetch) SMH_LAUNCH_FWD(true, true);
-        else SMH_LAUNCH_FWD(true, false);
+        if (prefetch) SMH_LAUNCH_FWD(true, kPrefetch, false);
+        else SMH_LAUNCH_FWD(true, kOneSet, false);
+    } else if (a.trace) {  // tools/trace_model.py: the stamped instantiations
+        if (skew) SMH_LAUNCH_FWD(false, kSkew, true);
+        else if (prefetch) SMH_LAUNCH_FWD(false, kPrefetch, true);
+        else SMH_LAUNCH_FWD(false, kOneSet, true);
+    } else if (skew) {
+        SMH_LAUNCH_FWD(false, kSkew, false);
     } else {
-        if (prefetch) SMH_LAUNCH_FWD(false, true);
-        else SMH_LAUNCH_FWD(false, false);
+        if (prefetch) SMH_LAUNCH_FWD(false, kPrefetch, false);
+        else SMH_LAUNCH_FWD(false, kOneSet, false);
     }
 #undef SMH_LAUNCH_FWD
     return smh::launch_status("b3mtl_forward_kernel");

@@ -320,6 +320,30 @@ def test_b3mtl_forward_vs_oracle(golden_model, ncls, W, N):
     assert np.allclose(outs[-1].sum(1), 1, atol=1e-5)
 
 
+@pytest.mark.parametrize("W,N", [(68, 1024), (68, 37), (99, 301), (249, 9), (30, 64)])
+def test_b3mtl_block_schedules_agree(W, N, monkeypatch):
+    """The two schedules of the 24 residual blocks (smh_tcn.hip) -- a barrier per block, and the skewed task list with tile
+    flags that inference runs by default -- hold the same network: outputs equal within the f32 re-ordering of the three
+    taps' sums, both within 1e-4 of the oracle, identical argmax; a partial last workgroup and short patches included."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w = b3_mtl.init_weights(seed=5, n_feat=240, patch_size=W, n_classes=3, randomize_bn=True)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=3)
+    m.set_weights_dict(w)
+    x = dev(np.random.default_rng(3).standard_normal((N, W, 240)).astype(np.float32))
+    outs = {}
+    for skew in ("1", "0"):
+        monkeypatch.setenv("SMH_TCN_SKEW", skew)
+        trunk = torch.empty((N, W, 32), device="cuda")
+        outs[skew] = (host(m.forward_device(x, trunk=trunk)), host(trunk))
+    np.testing.assert_allclose(outs["1"][0], outs["0"][0], atol=2e-5)
+    np.testing.assert_allclose(outs["1"][1], outs["0"][1], atol=5e-5, rtol=1e-5)
+    sel = np.r_[0:4, N - 4:N]
+    ref = np.concatenate(b3_mtl.forward(host(x)[sel], w, n_classes=3), axis=1)
+    for skew in ("1", "0"):
+        np.testing.assert_allclose(outs[skew][0][sel], ref, atol=1e-4)
+        assert np.array_equal(outs[skew][0][sel][:, -3:].argmax(1), ref[:, -3:].argmax(1))
+
+
 def test_get_lemaire_model_surface(tmp_path):
     from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
     model, lr = get_Lemaire_MTL_model(TR_STEPS=100, N_MELS=240, n_classes=3, patch_size=68, seed=3)

@@ -1,23 +1,15 @@
 #!/bin/bash
+# A/B of the whole bench step on one box: B3_MTL forward with the barrier schedule vs the skewed schedule
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-run() { python bench.py --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null | python -c "
-import json,sys
-try:
-    d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], {k:v['ms'] for k,v in d['kernels'].items() if k!='preprocess_signal'})
-except Exception as e: print('$1 failed (parity check)')"; }
-run "disjoint   "
-SMH_FEAT_OVERLAP=1 run "split8     "
-python - <<'PY'
-import os, sys
-sys.path.insert(0, ".")
-os.environ["TIMEONLY"] = "1"
-exec(open("tools/time_features.py").read().split("for rnd in range(2):")[0])
-for label, env in (("disjoint", {}), ("disjoint, plain stores", {"SMH_FEAT_STOP": "32"}), ("overlap8", {"SMH_FEAT_OVERLAP": "1"})):
-    for k in ("SMH_FEAT_STOP", "SMH_FEAT_OVERLAP"): os.environ.pop(k, None)
-    os.environ.update(env)
-    print("%-24s %.4f ms" % (label, t()), flush=True)
-    for stop, name in ((1, "walk"), (2, "write"), (3, "stats")):
-        os.environ["SMH_FEAT_STOP"] = str(stop + (32 if "plain" in label else 0))
-        print("    through %-8s %.4f ms" % (name, t()), flush=True)
+mkdir -p gpurun_out/r2
+for rep in 1 2 3; do
+for v in 0 1; do
+  SMH_TCN_SKEW=$v timeout -k 10 300 python bench.py --no-cpu-baseline --steps 50 --warmup 5 > gpurun_out/r2/ab_$v.json 2>/dev/null || exit 1
+  python - $v <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/r2/ab_%s.json" % sys.argv[1]))
+print("skew=%s  ms_per_step %.4f  model %.1f us (frac %.4f)" % (sys.argv[1], d["ms_per_step"], d["kernels"]["model"]["ms"] * 1000, d["roofline"]["frac"]))
 PY
+done
+done

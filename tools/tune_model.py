@@ -25,6 +25,8 @@ def t(nb, rounds=12):
 os.environ['SMH_TCN_NOHEADS']='1'
 print('no heads, blocks=0: %.4f ms' % t(0)); print('no heads, blocks=24: %.4f ms' % t(24))
 os.environ.pop('SMH_TCN_NOHEADS')
+if os.environ.get('TUNE_SHORT'):
+    print('blocks=0 %.4f  blocks=24 %.4f' % (t(0), t(24))); sys.exit(0)
 for nb in (None, 0, 2, 8, 16, 24):
     print("blocks=%s  %.4f ms" % (nb, t(nb)), flush=True)
 for n in (256, 512, 2048):
