@@ -822,6 +822,8 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
     const int half = rr >> 3, b = grp * 8 + (rr & 7);
     if (b >= B) return;
+    const bool w0_lds = !(stop_after & 16);  // bit 4 of the probe argument: layer-0 weights from L2 instead of an LDS copy
+    stop_after &= 15;
     const int ld = T | 1, R2 = 2 * rows;
     float *s_mean = img + (size_t)rows * ld;  // mean hi [rows], 1/scale [rows], mean lo [rows]
     float *s_inv = s_mean + rows, *s_lo = s_mean + 2 * rows;
@@ -902,7 +904,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         }
         while (mcur < m1) emit_first();
     }
-    if (x0p)  // this half's layer-0 weights -> LDS; consumed after several barriers
+    if (x0p && w0_lds)  // this half's layer-0 weights -> LDS; consumed after several barriers
         for (int i = threadIdx.x; i < rows * 32; i += blockDim.x) w0s[i] = w0[(size_t)half * rows * 32 + i];
     // maximum of the array -> the top_db floor in the power domain (see features_clip_kernel)
     float lim = 0.f;
@@ -966,7 +968,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     }
     __syncthreads();
     if (stop_after == 3) return;
-    if (x0p) {
+    auto layer0 = [&](auto wbase) {
         // this half's share of the network's first layer (features_clip_kernel has the derivation); one task = one 16-frame
         // tile with both 16-channel M-tiles
         const int q = lane >> 4, j = lane & 15;
@@ -980,7 +982,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             const int jt = 16 * u + j;
             int tt = s + min(jt, W - 1);
             tt -= (tt / T) * T;
-            const float *wr = w0s + (size_t)q * 32 + j;
+            const auto wr = wbase + (size_t)q * 32 + j;
             const float *tl = img + tt;
             f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = c0a, c1a = c0a, c1b = c0a;  // two chains per M-tile
             for (int s0 = 0; s0 < nst; s0 += 8) {
@@ -1013,6 +1015,10 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
                 *reinterpret_cast<f32x4 *>(o + 16) = c1a;
             }
         }
+    };
+    if (x0p) {
+        if (w0_lds) layer0(w0s);
+        else layer0(w0 + (size_t)half * rows * 32);  // weights straight from L2: 15 KB less LDS, three workgroups per CU
     }
     if (!patches) return;
     for (int p = 0; p < nP; ++p) {
@@ -1106,15 +1112,19 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         // combined by ds_add_f32 in a zeroed image (every bin read once, but 1.7x slower: LDS float atomics); software
         // pipelining of the walk's half-batches (slower: the loads already overlap across the two workgroups of a CU).
         size_t ldh = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows) + 64;
-        if (x0p) ldh += sizeof(float) * rows * 32;
+        // the layer-0 weights come straight from L2 (15 KB per half, shared by every workgroup): without an LDS copy a workgroup
+        // needs 49 KB and THREE share a CU (77 VGPRs: 6 waves per SIMD) -- 127-130 -> 113-115 us; SMH_FEAT_W0LDS=1: the copy
+        const bool w0_l2 = getenv("SMH_FEAT_W0LDS") == nullptr;
+        if (x0p && !w0_l2) ldh += sizeof(float) * rows * 32;
+        const int probe = (stop & 15) | (w0_l2 ? 16 : 0);
         const unsigned grid = 16u * (unsigned)((B + 7) / 8);
         if (fp.pend <= 2) {
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
-            hipLaunchKernelGGL(features_half_kernel<2>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, B, K, T,
+            hipLaunchKernelGGL(features_half_kernel<2>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, harmb, perc, B, K, T,
                                rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
         } else {
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
-            hipLaunchKernelGGL(features_half_kernel<4>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, B, K, T,
+            hipLaunchKernelGGL(features_half_kernel<4>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, harmb, perc, B, K, T,
                                rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
         }
         int rch = smh::launch_status("features_half_kernel");

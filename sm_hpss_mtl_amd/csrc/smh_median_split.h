@@ -290,7 +290,9 @@ struct SplitCfg {
 template <int LH, int LP>
 __global__ void __launch_bounds__((SplitCfg<LH, LP>::kThreads), (SplitCfg<LH, LP>::kWavesPerSimd))
 hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, float *__restrict__ perc, int K, int T,
-                         int TT, int stride, int nsh, int nsp, int nwh, int harm_tmajor, float, float) {
+                         int TT, int stride, int nsh, int nsp, int nwh, int harm_tmajor, float probe, float) {
+    // probe > 0 (tools/gpu/r2_fusion_bound.sh, SMH_MEDIAN_PROBE_NOLOAD): the tile is NOT staged -- what the medians cost when
+    // their input is already in LDS, i.e. the upper bound of fusing this kernel behind the STFT; the outputs are garbage
     extern __shared__ __attribute__((aligned(16))) float tile[];
     constexpr int HH = LH / 2;
     const int b = blockIdx.y;
@@ -306,7 +308,9 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
     // as one flat float2 stream with every load of a lane in flight at once (a single HBM round trip per workgroup)
     // and scattered to the odd-stride tile: element g = k*T + t lands at g + k*(stride - T).
     constexpr int kFlatBatch = SplitCfg<LH, LP>::kFlatBatch;
-    if (TT >= T && ((K * T) & 1) == 0 && K * T <= kFlatBatch * 2 * (int)blockDim.x) {
+    if (probe > 0.f) {
+        for (int i = threadIdx.x; i < K * stride; i += blockDim.x) tile[i] = (float)((i * 2654435761u) >> 8) * (1.0f / 16777216.f);
+    } else if (TT >= T && ((K * T) & 1) == 0 && K * T <= kFlatBatch * 2 * (int)blockDim.x) {
         const int n2 = (K * T) >> 1;
         const float2v *src = reinterpret_cast<const float2v *>(Sb);
         const unsigned magic = 0xFFFFFFFFu / (unsigned)T + 1u;  // g / T == umulhi(g, magic) for g * T < 2^32

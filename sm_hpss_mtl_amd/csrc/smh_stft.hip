@@ -253,7 +253,8 @@ __device__ __forceinline__ void dft25(float2 *x) {
 
 __global__ void __launch_bounds__(512)
 stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window, const float2 *__restrict__ twM,
-               const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F) {
+               const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe) {
+    // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
     constexpr int M = 200, K = 201;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float2 *tw = lds;             // M twiddles
@@ -327,11 +328,13 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         const float2 g = cmul(tw2[k], d);
         {
             const float re = 0.5f * (e.x + g.y), im = 0.5f * (e.y - g.x);
-            Sb[(unsigned)(k * T + f)] = mag(re, im);
+            const float v = mag(re, im);
+            if (!probe || v == -1.f) Sb[(unsigned)(k * T + f)] = v;
         }
         if (k != M / 2) {
             const float re = 0.5f * (e.x - g.y), im = 0.5f * (e.y + g.x);
-            Sb[(unsigned)((M - k) * T + f)] = mag(re, im);
+            const float v = mag(re, im);
+            if (!probe || v == -1.f) Sb[(unsigned)((M - k) * T + f)] = v;
         }
         f += dr;
         const int carry = f >= nf ? 1 : 0;
@@ -363,8 +366,9 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         const size_t lds = sizeof(float2) * (200 + 202 + 200 + (size_t)F * kMP400);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft400_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((T + F - 1) / F, B), block(nthreads);
+        static const int probe = getenv("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
         hipLaunchKernelGGL(stft400_kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
-                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F);
+                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe);
         return smh::launch_status("stft400_kernel");
     }
     StftArgs a;
