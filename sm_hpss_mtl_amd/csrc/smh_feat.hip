@@ -309,6 +309,7 @@ struct FeatPlan {
     int m0[smh_ctx::kMaxFeatSegs], m1[smh_ctx::kMaxFeatSegs], kbeg[smh_ctx::kMaxFeatSegs], kend[smh_ctx::kMaxFeatSegs],
         off[smh_ctx::kMaxFeatSegs];
     const float *plan;
+    unsigned long long *trace;  // tools/trace_features.py: phase stamps (s_memrealtime) per workgroup and wave, or nullptr
 };
 constexpr int kWalkBatch = 8;  // bins of loads in flight per lane
 
@@ -809,8 +810,10 @@ __global__ void fill_int_kernel(int *p, int n, int v) {
 // idles behind the stores.  NP = pending filters per bin: 2 for every Slaney bank whose filters are at least as wide as they
 // are apart (the reference's 120 mels over 201 bins: a frequency lies in exactly two triangles), 4 in general.
 // ---------------------------------------------------------------------------------------------------
-template <int NP>
-__global__ void __launch_bounds__(512)
+// TRACE: tools/trace_features.py only.  The stamps cost registers (93 instead of 78, i.e. the third workgroup per CU); the
+// TRACE build is therefore held to 80 VGPRs and spills ten of them: its timeline is indicative, not the plain build's.
+template <int NP, bool TRACE = false>
+__global__ void __launch_bounds__(512, (TRACE ? 6 : 1))
 features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int B, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
                      float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
@@ -830,6 +833,19 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)rows);  // 16 ints
     float *w0s = s_mean + 3 * (size_t)rows + 16;  // this half's layer-0 weights [rows][32] (x0p only)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    auto stamp = [&](int i) {  // (tools only) phase i of this wave: 100 MHz ticks + where the wave runs
+        if constexpr (!TRACE) return;
+        if (fp.trace) {
+            const int ws = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            unsigned long long *r = fp.trace + ((size_t)blockIdx.x * 8 + ws) * 8;
+            const unsigned long long tk = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) {
+                r[i] = tk;
+                if (i == 0) r[7] = __builtin_amdgcn_s_getreg((3 << 11) | 4 /* HW_REG_HW_ID */);
+            }
+        }
+    };
+    stamp(0);
     const size_t cb = (size_t)b * K * T;
     const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
     float mx = 0.f;  // maximum of this half's filter sums (sums of non-negative terms)
@@ -912,6 +928,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         int kx = ordered_key(mx);
         for (int off = 32; off > 0; off >>= 1) kx = max(kx, __shfl_xor(kx, off));
         if (lane == 0) smax[wave] = kx;
+        stamp(1);  // this wave's walk is done
         __syncthreads();  // also: the image is complete
         if (stop_after == 1) return;
         if (log_db) {
@@ -936,6 +953,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(g + (size_t)r * T) + t2);
         }
     }
+    stamp(2);  // dB + clip + write
     __syncthreads();
     if ((!patches && !x0p) || nP <= 0 || stop_after == 2) return;
     // StandardScaler statistics: four lanes per row, f64 partial sums (see std_patch_kernel)
@@ -966,7 +984,9 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         s_inv[r] = (float)(1.0 / scale);
         s_lo[r] = (float)(mean - (double)(float)mean);
     }
+    stamp(3);  // statistics
     __syncthreads();
+    stamp(4);
     if (stop_after == 3) return;
     auto layer0 = [&](auto wbase) {
         // this half's share of the network's first layer (features_clip_kernel has the derivation); one task = one 16-frame
@@ -1020,6 +1040,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         if (w0_lds) layer0(w0s);
         else layer0(w0 + (size_t)half * rows * 32);  // weights straight from L2: 15 KB less LDS, three workgroups per CU
     }
+    stamp(5);  // layer 0
     if (!patches) return;
     for (int p = 0; p < nP; ++p) {
         int s0 = p * shift;
@@ -1038,6 +1059,25 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
 }
 
 }  // namespace
+
+// tools/trace_features.py: phase stamps of features_half_kernel (8 words per wave, 8 waves per workgroup)
+static unsigned long long *g_feat_trace = nullptr;
+constexpr size_t kFeatTraceWords = (size_t)4096 * 8 * 8;
+extern "C" int smh_internal_feat_trace(int enable, unsigned long long *host, size_t words) {
+    if (enable && !g_feat_trace) {
+        if (hipMalloc((void **)&g_feat_trace, kFeatTraceWords * 8) != hipSuccess) return -1;
+        (void)hipMemset(g_feat_trace, 0, kFeatTraceWords * 8);
+    }
+    if (host && g_feat_trace) {
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(host, g_feat_trace, std::min(words, kFeatTraceWords) * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    if (!enable && g_feat_trace) {
+        (void)hipFree(g_feat_trace);
+        g_feat_trace = nullptr;
+    }
+    return 0;
+}
 
 namespace smh_feat {
 
@@ -1069,6 +1109,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
             fp.m0[i] = c->feat_m0[0][i], fp.m1[i] = c->feat_m1[0][i], fp.kbeg[i] = c->feat_kbeg[0][i],
             fp.kend[i] = c->feat_kend[0][i], fp.off[i] = c->feat_off[0][i];
         fp.plan = c->d_feat_plan;
+        fp.trace = nullptr;
         const int nwaves = std::min(16, walk_waves);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
         hipLaunchKernelGGL(hp_feat_walk_kernel, dim3(B), dim3(64 * nwaves), lds_walk, st, fp, c->cfg.log_db, S, harm, perc,
@@ -1103,6 +1144,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         fp.m0[i] = c->feat_m0[1][i], fp.m1[i] = c->feat_m1[1][i], fp.kbeg[i] = c->feat_kbeg[1][i],
         fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
     fp.plan = c->d_feat_plan;
+    fp.trace = g_feat_trace;
     const char *stop_ev = getenv("SMH_FEAT_STOP");  // tuning only
     const int stop = stop_ev ? atoi(stop_ev) : 0;
     if (pair) {
@@ -1118,15 +1160,28 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         if (x0p && !w0_l2) ldh += sizeof(float) * rows * 32;
         const int probe = (stop & 15) | (w0_l2 ? 16 : 0);
         const unsigned grid = 16u * (unsigned)((B + 7) / 8);
-        if (fp.pend <= 2) {
-            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
-            hipLaunchKernelGGL(features_half_kernel<2>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, harmb, perc, B, K, T,
-                               rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
-        } else {
-            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
-            hipLaunchKernelGGL(features_half_kernel<4>, dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, harmb, perc, B, K, T,
-                               rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
+        if (getenv("SMH_FEAT_OCC")) {  // tools only: what the runtime says about residency
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)features_half_kernel<2, false>, 512, ldh);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, (const void *)features_half_kernel<2, false>);
+            fprintf(stderr, "features_half_kernel<2>: dynamic LDS %zu B, regs %d, occupancy %d workgroups per CU\n", ldh, fa.numRegs, nb);
         }
+#define SMH_LAUNCH_HALF(NPV, TR)                                                                                          \
+    do {                                                                                                                \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<NPV, TR>,                                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));                      \
+        hipLaunchKernelGGL((features_half_kernel<NPV, TR>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S,  \
+                           harmb, perc, B, K, T, rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);     \
+    } while (0)
+        if (fp.trace) {
+            if (fp.pend <= 2) SMH_LAUNCH_HALF(2, true);
+            else SMH_LAUNCH_HALF(4, true);
+        } else {
+            if (fp.pend <= 2) SMH_LAUNCH_HALF(2, false);
+            else SMH_LAUNCH_HALF(4, false);
+        }
+#undef SMH_LAUNCH_HALF
         int rch = smh::launch_status("features_half_kernel");
         return rch ? rch : 1;
     }
