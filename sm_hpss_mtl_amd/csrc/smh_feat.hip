@@ -312,6 +312,7 @@ struct FeatPlan {
     unsigned long long *trace;  // tools/trace_features.py: phase stamps (s_memrealtime) per workgroup and wave, or nullptr
 };
 constexpr int kWalkBatch = 8;  // bins of loads in flight per lane
+constexpr int kHalfBatch = 8;   // the same in features_half_kernel (lane = frame pair)
 
 __global__ void __launch_bounds__(1024)
 hp_feat_walk_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const float *__restrict__ harm,
@@ -879,12 +880,12 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         // "own" = the median this half's mask favours (harm for H, perc for P): out = S own^2 / (own^2 + other^2)
         const float *Sb = S + cb + t0, *Pb = perc + cb + t0;
         const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
-        for (int k0 = kbeg; k0 < kend; k0 += kWalkBatch) {
-            f32x2 sv[kWalkBatch], pv[kWalkBatch], hv[kWalkBatch];
-            float4 wq[kWalkBatch];
-            int ne[kWalkBatch];
+        for (int k0 = kbeg; k0 < kend; k0 += kHalfBatch) {
+            f32x2 sv[kHalfBatch], pv[kHalfBatch], hv[kHalfBatch];
+            float4 wq[kHalfBatch];
+            int ne[kHalfBatch];
 #pragma unroll
-            for (int u = 0; u < kWalkBatch; ++u) {
+            for (int u = 0; u < kHalfBatch; ++u) {
                 const int kk = min(k0 + u, K - 1);
                 sv[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)kk * T);
                 pv[u] = *reinterpret_cast<const f32x2 *>(Pb + (size_t)kk * T);
@@ -894,7 +895,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
                 ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
             }
 #pragma unroll
-            for (int u = 0; u < kWalkBatch; ++u) {
+            for (int u = 0; u < kHalfBatch; ++u) {
                 if (k0 + u >= kend) break;
                 for (int i = 0; i < ne[u]; ++i) emit_first();
                 const f32x2 own = half ? pv[u] : hv[u], oth = half ? hv[u] : pv[u];
