@@ -1080,6 +1080,18 @@ extern "C" int smh_internal_feat_trace(int enable, unsigned long long *host, siz
     return 0;
 }
 
+// Residency of the bench path's feature kernel (tests/test_bench_path_gpu.py): workgroups of features_half_kernel<2> per CU
+// for a clip of T frames and `rows` mel rows per half with the layer-0 weights read from L2.  Three is what the measured
+// 113-118 us rest on (78 VGPRs, 49 KB of LDS); a build that needs more than 80 VGPRs silently drops to two and ~130 us.
+extern "C" int smh_internal_feat_residency(int rows, int T) {
+    const size_t ldh = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows) + 64;
+    if (hipFuncSetAttribute((const void *)features_half_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh) != hipSuccess)
+        return -1;
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)features_half_kernel<2, false>, 512, ldh) != hipSuccess) return -1;
+    return nb;
+}
+
 namespace smh_feat {
 
 MelTable mel_table(const smh_ctx *c) {

@@ -121,3 +121,16 @@ def test_other_ranks_clips_match_their_golden():
     out = hp.step(audio).cpu().numpy()
     gold = np.load(os.path.join(ROOT, "tests", "golden", "bench_golden.npz"))["logits_17x17"][3]
     assert np.max(np.abs(out[:gold.shape[0]] - gold)) <= bench.GOLDEN_LOGIT_TOL
+
+
+def test_feature_kernel_residency():
+    """The feature kernel of the bench path keeps THREE workgroups per CU (78 VGPRs, 49 KB of LDS: DESIGN 4.3); one more
+    register class or an LDS copy of the layer-0 weights and it drops to two, 113-118 us -> ~130 us, without any test noticing."""
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    lib = _lib.require_gpu()
+    f = lib.smh_internal_feat_residency
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int]
+    assert f(120, 98) == 3
+
