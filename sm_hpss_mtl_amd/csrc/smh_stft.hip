@@ -264,33 +264,65 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     const int b = blockIdx.y, t0 = blockIdx.x * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
     const int nthr = blockDim.x;
+    const float *clip = audio + (size_t)b * n_samples + (size_t)t0 * hop;
+    const int dq1 = nthr / 25, dr1 = nthr - dq1 * 25;
+    // Phase 1's audio is requested FIRST, for all of this thread's items at once (up to kRounds1 rounds of (frame, n2) items,
+    // 8 float2 each), then the twiddle / window tables travel to LDS: one trip to memory per workgroup where there were
+    // one for the tables and one per round (a round's loads used to be issued when the previous round's butterflies were done).
+    constexpr int kRounds1 = 3;
+    const bool ahead = 25 * nf <= kRounds1 * nthr;
+    float2 au[kRounds1][8];
+    int fr_[kRounds1], n2_[kRounds1];
+    if (ahead) {
+        int f = tid / 25, n2 = tid - (tid / 25) * 25;
+#pragma unroll
+        for (int r = 0; r < kRounds1; ++r) {
+            fr_[r] = f, n2_[r] = n2;
+            const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(min(f, nf - 1) * hop));
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) au[r][n1] = fr[25 * n1 + n2];
+            n2 += dr1;
+            const int carry = n2 >= 25 ? 1 : 0;
+            n2 -= 25 * carry;
+            f += dq1 + carry;
+        }
+    }
     for (int i = tid; i < M; i += nthr) {
         tw[i] = twM[i];
         win2[i] = reinterpret_cast<const float2 *>(window)[i];
     }
     for (int i = tid; i <= M; i += nthr) tw2[i] = tw2M[i];
     __syncthreads();
-    const float *clip = audio + (size_t)b * n_samples + (size_t)t0 * hop;
 
     // phase 1
-    const int dq1 = nthr / 25, dr1 = nthr - dq1 * 25;
-    for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf;) {
-        const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(f * hop));
-        float2 v[8];
+    auto butterfly1 = [&](float2 (&v)[8], int f, int n2) {
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const float2 a = fr[25 * n1 + n2], w = win2[25 * n1 + n2];
-            v[n1] = make_float2(a.x * w.x, a.y * w.y);
+            const float2 w = win2[25 * n1 + n2];
+            v[n1] = make_float2(v[n1].x * w.x, v[n1].y * w.y);
         }
         dft<8>(v);
         float2 *zf = Z + f * kMP400 + n2;
         zf[0] = v[0];
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmul(v[k1], tw[n2 * k1]);
-        n2 += dr1;
-        const int carry = n2 >= 25 ? 1 : 0;
-        n2 -= 25 * carry;
-        f += dq1 + carry;
+    };
+    if (ahead) {
+#pragma unroll
+        for (int r = 0; r < kRounds1; ++r)
+            if (fr_[r] < nf) butterfly1(au[r], fr_[r], n2_[r]);
+    } else {
+        for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf;) {
+            const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(f * hop));
+            float2 v[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) v[n1] = fr[25 * n1 + n2];
+            butterfly1(v, f, n2);
+            n2 += dr1;
+            const int carry = n2 >= 25 ? 1 : 0;
+            n2 -= 25 * carry;
+            f += dq1 + carry;
+        }
     }
     __syncthreads();
     // phase 2: read, barrier, compute, write in place (natural order); 8 * F <= blockDim.x items
