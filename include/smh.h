@@ -262,6 +262,9 @@ int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, floa
  * Neither is the parity path: smh_model_forward_f32 is. */
 int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream);
 int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, float *d_out, int split, void *stream);
+/* The same from the layer-0 partials of smh_features_l0_f32 (the bench fast path; layer 0 is then exact f32): d_x0p
+ * (N, 2, patch_size, 32) float32 as for smh_model_forward_x0_f32. */
+int smh_model_forward_x0_bf16(smh_model *m, const float *d_x0p, int N, float *d_out, int split, void *stream);
 int smh_model_get_weights(const smh_model *m, float *h_flat, size_t n, void *stream);
 
 /* ---- a13: Conv2D MTL baselines, inference forward (lib/proposed_architectures.py:425-511 Doukhan, :516-588

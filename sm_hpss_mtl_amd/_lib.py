@@ -92,6 +92,7 @@ SIGNATURES = {
     "smh_model_forward_x0_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "smh_model_forward_bf16": (_i, [_vp, _fp, _i, _fp, _vp]),
     "smh_model_forward_bf16_ex": (_i, [_vp, _fp, _i, _fp, _i, _vp]),
+    "smh_model_forward_x0_bf16": (_i, [_vp, _fp, _i, _fp, _i, _vp]),
     "smh_model_get_weights": (_i, [_vp, _vp, _sz, _vp]),
     "smh_cnn_create": (_i, [C.POINTER(CnnCfg), C.POINTER(_vp)]),
     "smh_cnn_destroy": (None, [_vp]),

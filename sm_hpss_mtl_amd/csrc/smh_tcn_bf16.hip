@@ -224,7 +224,33 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
     float *xa = lds, *xb = lds + (size_t)a.GRP * SX;
 
     // ---- initial Conv1D(32, 1) ------------------------------------------------------------------------------------
-    {
+    if (a.from_x0) {
+        // layer 0 was computed by the feature kernel in exact f32 (smh_features_l0_f32): X holds its two per-half partials
+        // (N, 2, T, 32); sum them, add the bias (the f32 kernel's prologue, smh_tcn.hip)
+        const float *bias0 = flat + off.w0_b;
+        constexpr int kX0R = 4;
+        const int n4 = GR * (C / 4);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += kX0R * blockDim.x) {
+            f32x4 pa[kX0R], pb[kX0R];
+#pragma unroll
+            for (int r = 0; r < kX0R; ++r) {
+                const int i = min(i0 + r * (int)blockDim.x, n4 - 1);
+                const int R = i >> 3, c4 = (i & 7) * 4;
+                const int g = R / T, t = R - g * T;
+                const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + t) * C + c4);
+                pa[r] = *reinterpret_cast<const f32x4 *>(p0);
+                pb[r] = *reinterpret_cast<const f32x4 *>(p0 + (size_t)T * C);
+            }
+#pragma unroll
+            for (int r = 0; r < kX0R; ++r) {
+                const int i = i0 + r * (int)blockDim.x;
+                if (i < n4) {
+                    const int R = i >> 3, c4 = (i & 7) * 4;
+                    *reinterpret_cast<f32x4 *>(xa + (size_t)R * SX + c4) = pa[r] + pb[r] + *reinterpret_cast<const f32x4 *>(bias0 + c4);
+                }
+            }
+        }
+    } else {
         bf16x8 *w0s = reinterpret_cast<bf16x8 *>(xb);  // layer-0 A operands staged in the not-yet-used buffer
         const int nW0 = pi.steps0 * 2 * 64;
         for (int i = threadIdx.x; i < nW0; i += blockDim.x) {
@@ -390,7 +416,7 @@ b3mtl_forward_bf16_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__re
 
 }  // namespace
 
-extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, float *d_out, int split, void *stream) {
+static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int split, int from_x0, void *stream) {
     SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_bf16: null argument");
     SMH_REQUIRE(N >= 0, "smh_model_forward_bf16: N=%d", N);
     SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_bf16: built for block_variant 0 only");
@@ -412,6 +438,7 @@ extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, 
     TcnArgs a;
     size_t lds;
     fill_args(m, N, &a, &lds);
+    a.from_x0 = from_x0;
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
     if (split) {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -425,6 +452,14 @@ extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, 
     return smh::launch_status("b3mtl_forward_bf16_kernel");
 }
 
+extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, float *d_out, int split, void *stream) {
+    return forward_bf16(m, d_x, N, d_out, split, 0, stream);
+}
+
 extern "C" int smh_model_forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, void *stream) {
-    return smh_model_forward_bf16_ex(m, d_x, N, d_out, 1, stream);
+    return forward_bf16(m, d_x, N, d_out, 1, 0, stream);
+}
+
+extern "C" int smh_model_forward_x0_bf16(smh_model *m, const float *d_x0p, int N, float *d_out, int split, void *stream) {
+    return forward_bf16(m, d_x0p, N, d_out, split, 1, stream);
 }

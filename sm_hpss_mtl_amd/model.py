@@ -237,8 +237,9 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_f32")
         return out
 
-    def forward_from_x0(self, x0p, out=None, trunk=None):
-        """Forward that starts from the per-half layer-0 partials (N, 2, W, 32) written by `Frontend.features_l0`."""
+    def forward_from_x0(self, x0p, out=None, trunk=None, dtype="f32"):
+        """Forward that starts from the per-half layer-0 partials (N, 2, W, 32) written by `Frontend.features_l0`.
+        dtype as for `forward_device`; with "bf16" / "bf16_plain" layer 0 stays exact f32 (it was computed by the feature kernel)."""
         if not (isinstance(x0p, torch.Tensor) and x0p.is_cuda and x0p.dtype == torch.float32):
             raise TypeError("forward_from_x0 expects a float32 CUDA tensor")
         x0p = x0p.contiguous()
@@ -250,6 +251,15 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         N = x0p.shape[0]
         if out is None:
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x0p.device)
+        if dtype in ("bf16", "bf16_plain"):
+            if trunk is not None:
+                raise ValueError("the trunk tap is only available on the f32 path")
+            _lib.check(self.lib.smh_model_forward_x0_bf16(
+                self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()), 1 if dtype == "bf16" else 0,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_bf16")
+            return out
+        if dtype != "f32":
+            raise ValueError("dtype must be 'f32', 'bf16' or 'bf16_plain'")
         _lib.check(self.lib.smh_model_forward_x0_f32(
             self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),

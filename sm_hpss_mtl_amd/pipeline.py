@@ -37,7 +37,7 @@ class HotPath:
         self.model_dtype = model_dtype
         if model_dtype not in ("f32", "bf16"):
             raise ValueError("model_dtype must be 'f32' or 'bf16'")
-        self.fuse_l0 = bool(fuse_l0) and model_dtype == "f32"
+        self.fuse_l0 = bool(fuse_l0)  # both network dtypes start from the layer-0 partials
         self.T = fe.num_frames(self.n_samples)
         if self.T < 1:
             raise ValueError("clip of %d samples is shorter than n_fft=%d" % (n_samples, fe.cfg.n_fft))
@@ -96,7 +96,7 @@ class HotPath:
         if record is not None:
             record[3].record()
         if self.fuse_l0:
-            m.forward_from_x0(self.x0p, out=self.logits, trunk=self.trunk)
+            m.forward_from_x0(self.x0p, out=self.logits, trunk=self.trunk, dtype=self.model_dtype)
         else:
             m.forward_device(self.patches, out=self.logits, trunk=self.trunk, dtype=self.model_dtype)
         if record is not None:

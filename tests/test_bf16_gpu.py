@@ -55,3 +55,29 @@ def test_bf16_operands_follow_weight_updates():
     assert not torch.equal(a, b) and float((b - ref).abs().max()) <= TOL_SPLIT
     with pytest.raises(ValueError):
         m.forward_device(x, dtype="fp8")
+
+
+@pytest.mark.parametrize("ncls,seed", [(3, 5), (5, 6)])
+def test_bf16_from_layer0_partials_end_to_end(ncls, seed):
+    """BASELINE config 5's shape on the bench fast path: f32 front end -> layer-0 partials (exact f32, feature kernel) ->
+    the bf16-operand network (smh_model_forward_x0_bf16), against the all-f32 path of the same clips and the oracle."""
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    from sm_hpss_mtl_amd.pipeline import HotPath
+    from sm_hpss_mtl_amd.synth import synth_clips
+    m, w = _model(ncls, 68, seed)
+    fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
+    B = 64
+    audio = torch.from_numpy(synth_clips(B, seed=40 + seed)).cuda()
+    ref = HotPath(fe, m, B, 16000, model_dtype="f32", keep_patches=True)
+    out32 = ref.step(audio).clone()
+    for dtype, tol in (("bf16", TOL_SPLIT),):
+        hp = HotPath(fe, m, B, 16000, model_dtype=dtype)
+        assert hp.fuse_l0 and hp.patches is None   # starts from the partials: no patch tensor on this path
+        got = hp.step(audio)
+        torch.cuda.synchronize()
+        err = float((got - out32).abs().max())
+        agree = float((got[:, -ncls:].argmax(1) == out32[:, -ncls:].argmax(1)).float().mean())
+        print("%s from x0 vs f32: max abs %.3e, argmax agreement %.4f" % (dtype, err, agree))
+        assert err <= tol and agree >= MIN_AGREE
+    small = np.concatenate(b3_mtl.forward(ref.patches[:8].cpu().numpy(), w, ncls), axis=1)
+    assert np.max(np.abs(got[:8].cpu().numpy() - small)) <= TOL_SPLIT
