@@ -750,25 +750,39 @@ __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const floa
 
 // l2(0.01) penalty of the Dense(16) kernels (the term Keras adds to the reported total loss), from the weights the
 // step ran with: one workgroup, f64 accumulation.
-__global__ void __launch_bounds__(1024) l2_penalty_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ out) {
-    __shared__ double sh[16];
-    double total = 0.0;
-    for (int h = 0; h < a.n_heads; ++h) {
-        double s = 0.0;
-        const float *w = flatw + a.off.head[h];
-        for (int i = threadIdx.x; i < a.D * kHidden; i += blockDim.x) s += (double)w[i] * (double)w[i];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
+// l2 = kL2 * sum over the heads' Dense(16) kernels of w^2, in f64: kL2Chunks workgroups per head write partial sums, the
+// last one to arrive (ticket) adds them in a fixed order -- one workgroup over the 3 x 34 816 weights took 50 us.
+constexpr int kL2Chunks = 16;
+__global__ void __launch_bounds__(256) l2_penalty_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ out,
+                                                         double *__restrict__ part, unsigned *__restrict__ ticket) {
+    __shared__ double sh[4];
+    __shared__ bool last;
+    const int h = blockIdx.x / kL2Chunks, c = blockIdx.x - h * kL2Chunks;
+    const int n = a.D * kHidden, per = (n + kL2Chunks - 1) / kL2Chunks;
+    const float *w = flatw + a.off.head[h];
+    double s = 0.0;
+    for (int i = c * per + threadIdx.x; i < min(n, (c + 1) * per); i += blockDim.x) s += (double)w[i] * (double)w[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double total = 0.0;
+        for (int hh = 0; hh < a.n_heads; ++hh) {
             double t = 0.0;
-            for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) t += sh[w2];
-            out[1 + h] = (float)((double)kL2 * t);  // per head: the sub-model Model(input, get_layer(h).output) carries only its own
+            for (int cc = 0; cc < kL2Chunks; ++cc) t += __builtin_nontemporal_load(part + hh * kL2Chunks + cc);
+            out[1 + hh] = (float)((double)kL2 * t);  // per head: the sub-model Model(input, get_layer(h).output) carries only its own
             total += t;
         }
+        out[0] = (float)((double)kL2 * total);
+        *ticket = 0;  // ready for the next step (stream order)
     }
-    if (threadIdx.x == 0) out[0] = (float)((double)kL2 * total);
 }
 
 struct Segment {
@@ -776,7 +790,12 @@ struct Segment {
     int kind;   // 0 plain, 1 l2-regularised Dense(16) kernel, 2 BN moving_mean, 3 BN moving_variance
     int aux;    // kinds 2/3: offset into the batch-statistics part of the gradient bucket
     int group;  // bit of `active_mask` this tensor belongs to: 0 trunk, 1 the '3C' Dense, 2 + h head h
+    // A tensor larger than kSegChunk elements is cut into pieces (one workgroup each: the three Dense(16) kernels of 34 816
+    // elements used to keep one workgroup busy for 75 us per pass while the chip idled); clipnorm is per TENSOR, so the
+    // optimiser pass adds the pieces' sums of squares, sumsq[p0 .. p0 + pn), in that fixed order.
+    int p0, pn;
 };
+constexpr unsigned kSegChunk = 4096;
 
 // pass 1: g = grad * grad_scale (+ l2 term), written back; per-tensor sum of squares for clipnorm
 __global__ void seg_sumsq_kernel(const Segment *__restrict__ segs, const float *__restrict__ w, float *__restrict__ grad,
@@ -820,7 +839,9 @@ __global__ void seg_opt_kernel(const Segment *__restrict__ segs, OptArgs o, floa
             w[s.off + i] = kBnMomentum * w[s.off + i] + (1.0f - kBnMomentum) * (bnstat[s.aux + i] * o.grad_scale);
         return;
     }
-    const float nrm = sqrtf(sumsq[blockIdx.x]);
+    float ss = 0.f;
+    for (int c = 0; c < s.pn; ++c) ss += sumsq[s.p0 + c];
+    const float nrm = sqrtf(ss);
     const float scale = (o.clipnorm > 0.f && nrm > o.clipnorm) ? o.clipnorm / nrm : 1.0f;
     for (unsigned i = threadIdx.x; i < s.size; i += blockDim.x) {
         const size_t k = (size_t)s.off + i;
@@ -855,6 +876,7 @@ struct smh_trainer {
     float *d_grad = nullptr, *d_bnstat = nullptr;
     float *d_vel = nullptr, *d_s2 = nullptr;  // optimiser state: momentum / first moment, second moment
     float *d_sumsq = nullptr, *d_scratch_out = nullptr, *d_wtr = nullptr;
+    double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
     Segment *d_segs = nullptr;
     long step = 0;             // optimiser steps taken (Adam / Nadam bias corrections)
     double m_schedule = 1.0;   // Nadam's running product of the momentum schedule
@@ -868,7 +890,13 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     const Offsets off = offsets(m);
     std::vector<Segment> segs;
     int group = 0;
-    auto add = [&](size_t o, size_t n, int kind, int aux) { segs.push_back(Segment{(unsigned)o, (unsigned)n, kind, aux, group}); };
+    auto add = [&](size_t o, size_t n, int kind, int aux) {
+        const int p0 = (int)segs.size(), pn = (int)((n + kSegChunk - 1) / kSegChunk);
+        for (int c = 0; c < pn; ++c) {
+            const size_t co = (size_t)c * kSegChunk, sz = std::min<size_t>(kSegChunk, n - co);
+            segs.push_back(Segment{(unsigned)(o + co), (unsigned)sz, kind, kind >= 2 ? aux + (int)co : aux, group, p0, pn});
+        }
+    };
     add(off.w0_k, (size_t)m->cfg.n_feat * C, 0, 0);
     add(off.w0_b, C, 0, 0);
     for (int b = 0; b < m->n_blocks; ++b) {
@@ -906,6 +934,8 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_sumsq, segs.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_scratch_out, (size_t)max_batch * m->out_dim * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_wtr, (size_t)m->n_blocks * 4 * C * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_l2part, (kMaxHeads * kL2Chunks + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(t->d_l2part, 0, (kMaxHeads * kL2Chunks + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Segment));
     if (e == hipSuccess) e = hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(t->d_vel, 0, m->n_params * sizeof(float));
@@ -924,6 +954,7 @@ extern "C" void smh_trainer_destroy(smh_trainer *t) {
     for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_s2, t->d_sumsq, t->d_scratch_out, t->d_wtr})
         (void)hipFree(p);
     (void)hipFree(t->d_segs);
+    (void)hipFree(t->d_l2part);
     delete t;
 }
 
@@ -962,7 +993,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.use_wt = 1;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
-    hipLaunchKernelGGL(l2_penalty_kernel, dim3(1), dim3(1024), 0, st, ba, m->d_flat, d_losses + m->n_heads + 3);
+    hipLaunchKernelGGL(l2_penalty_kernel, dim3(m->n_heads * kL2Chunks), dim3(256), 0, st, ba, m->d_flat, d_losses + m->n_heads + 3,
+                       t->d_l2part, reinterpret_cast<unsigned *>(t->d_l2part + kMaxHeads * kL2Chunks));
     rc = smh::launch_status("l2_penalty_kernel");
     if (rc) return rc;
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
