@@ -15,6 +15,8 @@
 #include <cstring>
 #include <vector>
 
+#include <type_traits>
+
 #include "smh_model.h"
 
 using namespace smh_tcn;
@@ -30,48 +32,94 @@ constexpr int kBThreads = 1024;
 
 using smh_tcn::HeadsArgs;
 
+// Sum over the 64 lanes, result in every lane, on the VALU's lane-permute paths: four DPP steps inside each row of 16 lanes
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then gfx950's v_permlane32_swap / v_permlane16_swap
+// across the rows.  (__shfl_xor is a ds_bpermute per step -- an LDS round trip, six of them in a dependent chain: the
+// heads kernel makes ~350 of these sums per step and spent most of its time in them.)
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds the sum of its row of 16
+    const unsigned u = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    const unsigned u2 = __float_as_uint(v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(u2, u2, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
 }
-// sum over the wave, then ONE LDS atomic per wave (all lanes must call it; idle lanes pass 0)
-__device__ __forceinline__ void wave_add(float *addr, float v) {
+// sum over the wave, added to THIS wave's own accumulator row (all lanes must call it; idle lanes pass 0): a plain
+// read-add-write by lane 0 -- no other wave touches the row, so no float atomic (ds_add_f32 is slow and orders nothing);
+// the rows are added up in wave order afterwards, which also makes the sums reproducible
+__device__ __forceinline__ void wave_add(float *row, int q, float v) {
     v = wave_sum_f(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(addr, v);
+    if ((threadIdx.x & 63) == 0) row[q] += v;
 }
+// accumulator slots of heads_train_kernel (per wave, then totals)
+enum { Q_SUM1 = 0, Q_SUM2 = 64, Q_DGAMMA = 128, Q_DBETA = 192, Q_DBIAS = 256, Q_DWO = 320, Q_DBO = Q_DWO + smh_tcn::kMaxHeads * smh_tcn::kHidden * 3,
+       Q_LOSS = Q_DBO + smh_tcn::kMaxHeads * 3, Q_DB3 = Q_LOSS + smh_tcn::kMaxHeads + 2, Q_ACC = Q_DB3 + 8, kQ = Q_ACC + smh_tcn::kMaxHeads };
 
 // Single workgroup: the batch-statistics part of the network is tiny (N x 51 values).  Every reduction over the
 // batch is spread over the lanes (16 lanes per hidden unit for the statistics; one head at a time with wave-level
 // sums for the gradients of the small tensors) -- a thread looping over the whole batch was 60 % of this kernel.
+// STAGED (the batch fits: N <= kHeadsStageMax): `pre` and the targets are copied to LDS once, coalesced and all in flight,
+// and every later access -- most of them with lane = sample, i.e. 320-byte strides in global memory, 64 cache lines per
+// wave load -- is an LDS read at an odd stride; d loss / d pre is built in place in that tile and leaves in one coalesced
+// copy; dxh is kept transposed ([unit][sample]: coalesced both ways).  One workgroup on one CU is latency-bound: the
+// global-memory form of this kernel took 181 us for 510 patches.
+template <bool STAGED>
 __global__ void __launch_bounds__(1024)
 heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__restrict__ y, const float *__restrict__ hp,
                    const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
                    float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses) {
-    __shared__ float s_mean[64], s_inv[64], s_sum1[64], s_sum2[64], s_dgamma[64], s_dbeta[64], s_dbias[64];
-    __shared__ float s_dwo[kMaxHeads * kHidden * 3], s_dbo[kMaxHeads * 3], s_loss[kMaxHeads + 2], s_db3[8], s_acc[kMaxHeads];
+    extern __shared__ __attribute__((aligned(16))) float stage[];
+    __shared__ float s_mean[64], s_inv[64];
+    __shared__ float red[16][kQ], tot[kQ];  // per-wave accumulator rows (blockDim.x <= 1024), their totals
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int N = a.N, ncls = a.n_classes, nh = a.n_heads, NJ = nh * kHidden;
-    for (int i = tid; i < 64; i += nt) s_sum1[i] = s_sum2[i] = s_dgamma[i] = s_dbeta[i] = s_dbias[i] = 0.f;
-    for (int i = tid; i < kMaxHeads * kHidden * 3; i += nt) s_dwo[i] = 0.f;
-    if (tid < kMaxHeads * 3) s_dbo[tid] = 0.f;
-    if (tid < kMaxHeads + 2) s_loss[tid] = 0.f;
-    if (tid < kMaxHeads) s_acc[tid] = 0.f;
-    if (tid < 8) s_db3[tid] = 0.f;
+    float *row = red[tid >> 6];
+    auto totals = [&]() {  // every wave's row -> tot, in wave order; called by all threads between barriers
+        __syncthreads();
+        for (int q = tid; q < kQ; q += nt) {
+            float v = 0.f;
+            for (int w = 0; w < (nt >> 6); ++w) v += red[w][q];
+            tot[q] = v;
+        }
+        __syncthreads();
+    };
+    const int N = a.N, ncls = a.n_classes, nh = a.n_heads, NJ = nh * kHidden, NHc = ncls + NJ;
+    const int PST = NHc | 1, YST = a.out_dim | 1;  // odd row strides: lane = sample reads are conflict-free
+    float *tile = stage, *ty = stage + (size_t)(STAGED ? N : 0) * PST;
+    auto P = [&](int n, int c) -> float { return STAGED ? tile[n * PST + c] : pre[(size_t)n * kPS + c]; };
+    auto Y = [&](int n, int c) -> float { return STAGED ? ty[n * YST + c] : y[(size_t)n * a.out_dim + c]; };
+    if constexpr (STAGED) {
+        for (int i = tid; i < N * NHc; i += nt) {
+            const int n = i / NHc, c = i - n * NHc;
+            tile[n * PST + c] = pre[(size_t)n * kPS + c];
+        }
+        for (int i = tid; i < N * a.out_dim; i += nt) {
+            const int n = i / a.out_dim, c = i - n * a.out_dim;
+            ty[n * YST + c] = y[i];
+        }
+    }
+    for (int i = tid; i < 16 * kQ; i += nt) (&red[0][0])[i] = 0.f;
+    if constexpr (STAGED) __syncthreads();
     // A: batch statistics of every hidden unit (population variance, two passes): 16 lanes per unit
     {
         const int j = tid >> 4, sub = tid & 15;
         const bool on = j < NJ;
         float s = 0.f;
         if (on)
-            for (int n = sub; n < N; n += 16) s += pre[(size_t)n * kPS + ncls + j];
+            for (int n = sub; n < N; n += 16) s += P(n, ncls + j);
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / (float)N;
         float q = 0.f;
         if (on)
             for (int n = sub; n < N; n += 16) {
-                const float d = pre[(size_t)n * kPS + ncls + j] - mean;
+                const float d = P(n, ncls + j) - mean;
                 q += d * d;
             }
 #pragma unroll
@@ -102,18 +150,28 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
             float xh[kHidden], bn[kHidden], ad[kHidden], dm[kHidden];
             float zo[3] = {0.f, 0.f, 0.f};
             for (int c = 0; c < od; ++c) zo[c] = bo[c];
+            if (drop) {  // this sample's 16 masks: four float4 (64 contiguous bytes)
+                const float4 *dp = reinterpret_cast<const float4 *>(drop + ((size_t)nc * nh + h) * kHidden);
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const float4 v = dp[i4];
+                    dm[4 * i4] = v.x, dm[4 * i4 + 1] = v.y, dm[4 * i4 + 2] = v.z, dm[4 * i4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kHidden; ++i) dm[i] = 1.0f;
+            }
 #pragma unroll
             for (int i = 0; i < kHidden; ++i) {
                 const int j = h * kHidden + i;
-                xh[i] = (pre[(size_t)nc * kPS + ncls + j] - s_mean[j]) * s_inv[j];
+                xh[i] = (P(nc, ncls + j) - s_mean[j]) * s_inv[j];
                 bn[i] = xh[i] * gamma[i] + beta[i];
-                dm[i] = drop ? drop[((size_t)nc * nh + h) * kHidden + i] : 1.0f;
                 ad[i] = fmaxf(bn[i], 0.f) * dm[i];
                 for (int c = 0; c < od; ++c) zo[c] = fmaf(ad[i], wo[i * od + c], zo[c]);
             }
             float dzo[3] = {0.f, 0.f, 0.f}, lsum = 0.f, hit = 0.f;
             for (int c = 0; c < od; ++c) {
-                const float t = y[(size_t)nc * a.out_dim + col + c];
+                const float t = Y(nc, col + c);
                 if (a.head_sigmoid[h]) {
                     const float o = 1.0f / (1.0f + expf(-zo[c]));
                     hit += ((o > 0.5f) == (t > 0.5f)) ? 1.0f : 0.f;  // Keras binary_accuracy, threshold 0.5
@@ -128,36 +186,54 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                     dzo[c] = 2.0f * d / (float)(N * od);
                 }
                 dzo[c] = on ? dzo[c] * a.lw[h] : 0.f;
-                wave_add(&s_dbo[h * 3 + c], dzo[c]);
+                wave_add(row, Q_DBO + h * 3 + c, dzo[c]);
             }
-            wave_add(&s_loss[h], on ? lsum / (float)(N * od) : 0.f);
-            wave_add(&s_acc[h], on ? hit / (float)(N * od) : 0.f);
+            wave_add(row, Q_LOSS + h, on ? lsum / (float)(N * od) : 0.f);
+            wave_add(row, Q_ACC + h, on ? hit / (float)(N * od) : 0.f);
 #pragma unroll
             for (int i = 0; i < kHidden; ++i) {
                 const int j = h * kHidden + i;
                 float da = 0.f;
                 for (int c = 0; c < od; ++c) {
                     da = fmaf(dzo[c], wo[i * od + c], da);
-                    wave_add(&s_dwo[(h * kHidden + i) * 3 + c], ad[i] * dzo[c]);
+                    wave_add(row, Q_DWO + (h * kHidden + i) * 3 + c, ad[i] * dzo[c]);
                 }
                 const float dbn = (on && bn[i] > 0.f) ? da * dm[i] : 0.f;
                 const float dxhat = dbn * gamma[i];
-                if (on) dxh[(size_t)n * kPS + j] = dxhat;
-                wave_add(&s_dgamma[j], dbn * xh[i]);
-                wave_add(&s_dbeta[j], dbn);
-                wave_add(&s_sum1[j], dxhat);
-                wave_add(&s_sum2[j], dxhat * xh[i]);
+                if (on) {
+                    if constexpr (STAGED) dxh[(size_t)j * N + n] = dxhat;  // [unit][sample]
+                    else dxh[(size_t)n * kPS + j] = dxhat;
+                }
+                wave_add(row, Q_DGAMMA + j, dbn * xh[i]);
+                wave_add(row, Q_DBETA + j, dbn);
+                wave_add(row, Q_SUM1 + j, dxhat);
+                wave_add(row, Q_SUM2 + j, dxhat * xh[i]);
             }
         }
     }
-    __syncthreads();
-    // C: BN backward to the Dense(16) pre-activations
-    for (int it = tid; it < N * NJ; it += nt) {
-        const int n = it / NJ, j = it - n * NJ;
-        const float xhat = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
-        const float d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)n * kPS + j] - s_sum1[j] - xhat * s_sum2[j]);
-        dpre[(size_t)n * kPS + ncls + j] = d;
-        atomicAdd(&s_dbias[j], d);
+    totals();  // sum1 / sum2 of every unit for the BatchNorm backward
+    if constexpr (STAGED) {
+        // C: BN backward to the Dense(16) pre-activations, lanes over the samples of one unit; d replaces pre in the tile
+        const int NR = ((N + 63) >> 6) << 6;  // whole waves per unit: the wave sum below needs every lane
+        for (int it = tid; it < NJ * NR; it += nt) {
+            const int j = it / NR, n = it - j * NR;
+            float d = 0.f;
+            if (n < N) {
+                const float xhat = (tile[n * PST + ncls + j] - s_mean[j]) * s_inv[j];
+                d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)j * N + n] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
+                tile[n * PST + ncls + j] = d;
+            }
+            wave_add(row, Q_DBIAS + j, d);
+        }
+    } else {
+        // C: BN backward to the Dense(16) pre-activations
+        for (int it = tid; it < N * NJ; it += nt) {
+            const int n = it / NJ, j = it - n * NJ;
+            const float xhat = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
+            const float d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)n * kPS + j] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
+            dpre[(size_t)n * kPS + ncls + j] = d;
+            atomicAdd(&red[0][Q_DBIAS + j], d);  // lanes of one wave hold different units here
+        }
     }
     // D: softmax + categorical cross-entropy (lanes over the samples, wave-reduced sums)
     for (int n0 = 0; n0 < N; n0 += nt) {
@@ -165,53 +241,64 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         const bool on = n < N;
         const int nc = on ? n : N - 1;
         float mx = -INFINITY, p[8], t[8];
-        for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, pre[(size_t)nc * kPS + c]);
+        for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, P(nc, c));
         float den = 0.f;
-        for (int c = 0; c < ncls; ++c) den += (p[c] = expf(pre[(size_t)nc * kPS + c] - mx));
+        for (int c = 0; c < ncls; ++c) den += (p[c] = expf(P(nc, c) - mx));
         int am = 0, at = 0;
         float l = 0.f;
         for (int c = 0; c < ncls; ++c) {
             p[c] /= den;
-            t[c] = y[(size_t)nc * a.out_dim + (a.out_dim - ncls) + c];
+            t[c] = Y(nc, (a.out_dim - ncls) + c);
             l -= t[c] * logf(fminf(fmaxf(p[c], kKerasEps), 1.0f - kKerasEps));
             if (p[c] > p[am]) am = c;
             if (t[c] > t[at]) at = c;
         }
         for (int c = 0; c < ncls; ++c) {
             const float d = on ? (p[c] - t[c]) / (float)N * a.lw[nh] : 0.f;
-            if (on) dpre[(size_t)n * kPS + c] = d;
-            wave_add(&s_db3[c], d);
+            if (on) {
+                if constexpr (STAGED) tile[n * PST + c] = d;  // a lane's own row: its reads of P(n, .) are done
+                else dpre[(size_t)n * kPS + c] = d;
+            }
+            wave_add(row, Q_DB3 + c, d);
         }
-        if (on)
-            for (int c = ncls + NJ; c < kPS; ++c) dpre[(size_t)n * kPS + c] = 0.f;
-        wave_add(&s_loss[nh], on ? l / (float)N : 0.f);
-        wave_add(&s_loss[nh + 1], (on && am == at) ? 1.0f / (float)N : 0.f);
+        if constexpr (!STAGED)
+            if (on)
+                for (int c = ncls + NJ; c < kPS; ++c) dpre[(size_t)n * kPS + c] = 0.f;
+        wave_add(row, Q_LOSS + nh, on ? l / (float)N : 0.f);
+        wave_add(row, Q_LOSS + nh + 1, (on && am == at) ? 1.0f / (float)N : 0.f);
     }
-    __syncthreads();
+    if constexpr (STAGED) {
+        __syncthreads();
+        for (int i = tid; i < N * kPS; i += nt) {  // d loss / d pre leaves in one coalesced copy
+            const int n = i / kPS, c = i - n * kPS;
+            dpre[i] = c < NHc ? tile[n * PST + c] : 0.f;
+        }
+    }
+    totals();
     // E: gradients of the small tensors (this workgroup is their only writer) and the losses
     for (int j = tid; j < NJ; j += nt) {
         const int h = j / kHidden, i = j % kHidden;
         float *gh = grad + a.goff_head[h] + (size_t)a.D * kHidden;  // after the dense kernel
-        gh[i] = s_dbias[j];
-        gh[16 + i] = s_dgamma[j];
-        gh[32 + i] = s_dbeta[j];
+        gh[i] = tot[Q_DBIAS + j];
+        gh[16 + i] = tot[Q_DGAMMA + j];
+        gh[32 + i] = tot[Q_DBETA + j];
         const int od = a.head_odim[h];
-        for (int c = 0; c < od; ++c) gh[16 + 64 + i * od + c] = s_dwo[j * 3 + c];
-        if (i < od) gh[16 + 64 + kHidden * od + i] = s_dbo[h * 3 + i];
+        for (int c = 0; c < od; ++c) gh[16 + 64 + i * od + c] = tot[Q_DWO + j * 3 + c];
+        if (i < od) gh[16 + 64 + kHidden * od + i] = tot[Q_DBO + h * 3 + i];
     }
-    if (tid < ncls) grad[a.goff_c3b + tid] = s_db3[tid];
+    if (tid < ncls) grad[a.goff_c3b + tid] = tot[Q_DB3 + tid];
     if (tid == 0) {
         float total = 0.f;
         for (int h = 0; h < nh; ++h) {
-            losses[h] = s_loss[h];
-            total += a.lw[h] * s_loss[h];
+            losses[h] = tot[Q_LOSS + h];
+            total += a.lw[h] * tot[Q_LOSS + h];
         }
-        losses[nh] = s_loss[nh];
-        total += a.lw[nh] * s_loss[nh];
+        losses[nh] = tot[Q_LOSS + nh];
+        total += a.lw[nh] * tot[Q_LOSS + nh];
         losses[nh + 1] = total;           // without the l2 term (losses[nh + 3], l2_penalty_kernel)
-        losses[nh + 2] = s_loss[nh + 1];  // 3C accuracy
+        losses[nh + 2] = tot[Q_LOSS + nh + 1];  // 3C accuracy
         if (a.ext_losses)                 // B3_MTL trainer: [2 nh + 4 + h] = binary accuracy of head h (training-mode outputs)
-            for (int h = 0; h < nh; ++h) losses[2 * nh + 4 + h] = s_acc[h];
+            for (int h = 0; h < nh; ++h) losses[2 * nh + 4 + h] = tot[Q_ACC + h];
     }
 }
 
@@ -864,7 +951,15 @@ __global__ void seg_opt_kernel(const Segment *__restrict__ segs, OptArgs o, floa
 
 int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop,
                                 float *dpre, float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st) {
-    hipLaunchKernelGGL(heads_train_kernel, dim3(1), dim3(1024), 0, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+    const int NHc = a.n_classes + a.n_heads * kHidden;
+    const size_t lds = sizeof(float) * ((size_t)a.N * (NHc | 1) + (size_t)a.N * (a.out_dim | 1));
+    // 160 KB of LDS per CU minus the kernel's static 37 KB (per-wave accumulator rows): 3-class batches up to 528 patches
+    if (lds <= 122 * 1024 && !getenv("SMH_HEADS_GLOBAL")) {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)heads_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(heads_train_kernel<true>, dim3(1), dim3(1024), lds, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+    } else {
+        hipLaunchKernelGGL(heads_train_kernel<false>, dim3(1), dim3(1024), 0, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+    }
     return smh::launch_status("heads_train_kernel");
 }
 

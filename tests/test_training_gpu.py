@@ -269,7 +269,8 @@ def test_growing_the_trainer_keeps_the_optimiser_state():
     for k in res[0]:
         delta = np.abs(res[1][k] - w[k]).max()
         # same arithmetic either way; only the order of the float atomics in the weight gradients differs run to run
-        assert np.abs(res[0][k] - res[1][k]).max() <= 1e-3 * delta + 1e-7, k
+        # (tools/flake_probe.py: that order alone moves single elements by up to 2.1e-3 of the update, in discrete steps)
+        assert np.abs(res[0][k] - res[1][k]).max() <= 5e-3 * delta + 1e-7, k
     # and momentum really was there: a fresh optimiser on the third step gives a visibly different update
     m = B3MTL(n_feat=240, patch_size=68, n_classes=3, TR_STEPS=10)
     m.set_weights_dict(w)
