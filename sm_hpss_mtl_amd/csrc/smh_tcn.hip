@@ -853,7 +853,9 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     int gmax = 272 / T;
     if (gmax < 1) gmax = 1;
     if (gmax > kMaxG) gmax = kMaxG;
-    int G = N / 256;
+    // ceil(N / 256): as few workgroups as there are CUs when the batch allows it -- 510 patches as 255 workgroups of two run one
+    // round of the chip; as 510 workgroups of one (floor) they ran two, each with a quarter-empty fifth tile
+    int G = (N + 255) / 256;
     if (G < 1) G = 1;
     if (G > gmax) G = gmax;
     if (const char *ev = getenv("SMH_TCN_G")) {  // tuning only (tools/tune_model.py)
