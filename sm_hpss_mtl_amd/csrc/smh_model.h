@@ -48,6 +48,7 @@ struct HeadsArgs {
     size_t goff_c3b;              // canonical offset of the 3C bias
     size_t hp_off[kMaxHeads];     // offset in `hp` of each head's [gamma, beta, mean, var (16 each), out kernel, out bias]
     int ext_losses;               // 1: `losses` has 3 n_heads + 4 floats and gets the per-head binary accuracies at [2 nh + 4 + h]
+    int stamps;                   // tools only (SMH_HEADS_STAMPS): thread 0 prints the phase durations (100 MHz ticks)
 };
 int launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop, float *dpre,
                        float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st);

@@ -54,9 +54,10 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // sum over the wave, added to THIS wave's own accumulator row (all lanes must call it; idle lanes pass 0): a plain
 // read-add-write by lane 0 -- no other wave touches the row, so no float atomic (ds_add_f32 is slow and orders nothing);
 // the rows are added up in wave order afterwards, which also makes the sums reproducible
-__device__ __forceinline__ void wave_add(float *row, int q, float v) {
+// first = this wave's first contribution to slot q: a plain store (the read-add-write chain is an LDS round trip per sum)
+__device__ __forceinline__ void wave_add(float *row, int q, float v, bool first = false) {
     v = wave_sum_f(v);
-    if ((threadIdx.x & 63) == 0) row[q] += v;
+    if ((threadIdx.x & 63) == 0) row[q] = first ? v : row[q] + v;
 }
 // accumulator slots of heads_train_kernel (per wave, then totals)
 enum { Q_SUM1 = 0, Q_SUM2 = 64, Q_DGAMMA = 128, Q_DBETA = 192, Q_DBIAS = 256, Q_DWO = 320, Q_DBO = Q_DWO + smh_tcn::kMaxHeads * smh_tcn::kHidden * 3,
@@ -70,8 +71,10 @@ enum { Q_SUM1 = 0, Q_SUM2 = 64, Q_DGAMMA = 128, Q_DBETA = 192, Q_DBIAS = 256, Q_
 // wave load -- is an LDS read at an odd stride; d loss / d pre is built in place in that tile and leaves in one coalesced
 // copy; dxh is kept transposed ([unit][sample]: coalesced both ways).  One workgroup on one CU is latency-bound: the
 // global-memory form of this kernel took 181 us for 510 patches.
-template <bool STAGED>
-__global__ void __launch_bounds__(1024)
+// THREADS: 512 when the batch fits (one sample per lane in the per-head pass, 256 VGPRs: at 1024 threads the pass lives on
+// 128 VGPRs and spills 46 of them into its inner loops), else 1024.
+template <bool STAGED, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__restrict__ y, const float *__restrict__ hp,
                    const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
                    float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses) {
@@ -80,6 +83,10 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     __shared__ float red[16][kQ], tot[kQ];  // per-wave accumulator rows (blockDim.x <= 1024), their totals
     const int tid = threadIdx.x, nt = blockDim.x;
     float *row = red[tid >> 6];
+    unsigned long long tk[8];
+    int ntk = 0;
+    auto stamp = [&]() { if (a.stamps && tid == 0 && ntk < 8) tk[ntk++] = __builtin_amdgcn_s_memrealtime(); };
+    stamp();
     auto totals = [&]() {  // every wave's row -> tot, in wave order; called by all threads between barriers
         __syncthreads();
         for (int q = tid; q < kQ; q += nt) {
@@ -106,9 +113,10 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     }
     for (int i = tid; i < 16 * kQ; i += nt) (&red[0][0])[i] = 0.f;
     if constexpr (STAGED) __syncthreads();
+    stamp();  // staged
     // A: batch statistics of every hidden unit (population variance, two passes): 16 lanes per unit
-    {
-        const int j = tid >> 4, sub = tid & 15;
+    for (int j0 = 0; j0 < NJ; j0 += nt >> 4) {
+        const int j = j0 + (tid >> 4), sub = tid & 15;
         const bool on = j < NJ;
         float s = 0.f;
         if (on)
@@ -134,6 +142,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         }
     }
     __syncthreads();
+    stamp();  // A
     // B: one head at a time, lanes over the samples: forward through BN / relu / dropout / output Dense, loss,
     // gradients; sums over the batch are wave-reduced before they touch LDS
     for (int h = 0; h < nh; ++h) {
@@ -186,17 +195,17 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                     dzo[c] = 2.0f * d / (float)(N * od);
                 }
                 dzo[c] = on ? dzo[c] * a.lw[h] : 0.f;
-                wave_add(row, Q_DBO + h * 3 + c, dzo[c]);
+                wave_add(row, Q_DBO + h * 3 + c, dzo[c], n0 == 0);
             }
-            wave_add(row, Q_LOSS + h, on ? lsum / (float)(N * od) : 0.f);
-            wave_add(row, Q_ACC + h, on ? hit / (float)(N * od) : 0.f);
+            wave_add(row, Q_LOSS + h, on ? lsum / (float)(N * od) : 0.f, n0 == 0);
+            wave_add(row, Q_ACC + h, on ? hit / (float)(N * od) : 0.f, n0 == 0);
 #pragma unroll
             for (int i = 0; i < kHidden; ++i) {
                 const int j = h * kHidden + i;
                 float da = 0.f;
                 for (int c = 0; c < od; ++c) {
                     da = fmaf(dzo[c], wo[i * od + c], da);
-                    wave_add(row, Q_DWO + (h * kHidden + i) * 3 + c, ad[i] * dzo[c]);
+                    wave_add(row, Q_DWO + (h * kHidden + i) * 3 + c, ad[i] * dzo[c], n0 == 0);
                 }
                 const float dbn = (on && bn[i] > 0.f) ? da * dm[i] : 0.f;
                 const float dxhat = dbn * gamma[i];
@@ -204,26 +213,44 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                     if constexpr (STAGED) dxh[(size_t)j * N + n] = dxhat;  // [unit][sample]
                     else dxh[(size_t)n * kPS + j] = dxhat;
                 }
-                wave_add(row, Q_DGAMMA + j, dbn * xh[i]);
-                wave_add(row, Q_DBETA + j, dbn);
-                wave_add(row, Q_SUM1 + j, dxhat);
-                wave_add(row, Q_SUM2 + j, dxhat * xh[i]);
+                wave_add(row, Q_DGAMMA + j, dbn * xh[i], n0 == 0);
+                wave_add(row, Q_DBETA + j, dbn, n0 == 0);
             }
         }
     }
-    totals();  // sum1 / sum2 of every unit for the BatchNorm backward
+    totals();  // dbeta / dgamma of every unit; the BatchNorm backward's sums follow from them: dxhat = gamma dbn, so
+    // sum_n dxhat = gamma dbeta and sum_n dxhat xhat = gamma dgamma (32 fewer wave sums per head)
+    for (int j = tid; j < NJ; j += nt) {
+        const float gm = hp[a.hp_off[j / kHidden] + (j % kHidden)];
+        tot[Q_SUM1 + j] = gm * tot[Q_DBETA + j];
+        tot[Q_SUM2 + j] = gm * tot[Q_DGAMMA + j];
+    }
+    __syncthreads();
+    stamp();  // B
     if constexpr (STAGED) {
         // C: BN backward to the Dense(16) pre-activations, lanes over the samples of one unit; d replaces pre in the tile
         const int NR = ((N + 63) >> 6) << 6;  // whole waves per unit: the wave sum below needs every lane
-        for (int it = tid; it < NJ * NR; it += nt) {
-            const int j = it / NR, n = it - j * NR;
-            float d = 0.f;
-            if (n < N) {
-                const float xhat = (tile[n * PST + ncls + j] - s_mean[j]) * s_inv[j];
-                d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)j * N + n] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
-                tile[n * PST + ncls + j] = d;
+        constexpr int kCI = 8;  // dxh values requested ahead per thread (one L2 trip per eight iterations instead of one each)
+        for (int it0 = tid; it0 < NJ * NR; it0 += kCI * nt) {
+            float dv[kCI];
+#pragma unroll
+            for (int e = 0; e < kCI; ++e) {
+                const int it = it0 + e * nt, j = it / NR, n = it - j * NR;
+                dv[e] = (it < NJ * NR && n < N) ? dxh[(size_t)j * N + n] : 0.f;
             }
-            wave_add(row, Q_DBIAS + j, d);
+#pragma unroll
+            for (int e = 0; e < kCI; ++e) {
+                const int it = it0 + e * nt;
+                if (it >= NJ * NR) break;  // wave-uniform (NR and nt are multiples of 64)
+                const int j = it / NR, n = it - j * NR;
+                float d = 0.f;
+                if (n < N) {
+                    const float xhat = (tile[n * PST + ncls + j] - s_mean[j]) * s_inv[j];
+                    d = s_inv[j] / (float)N * ((float)N * dv[e] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
+                    tile[n * PST + ncls + j] = d;
+                }
+                wave_add(row, Q_DBIAS + j, d, true);  // a wave meets a unit once: NR <= nt
+            }
         }
     } else {
         // C: BN backward to the Dense(16) pre-activations
@@ -235,6 +262,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
             atomicAdd(&red[0][Q_DBIAS + j], d);  // lanes of one wave hold different units here
         }
     }
+    stamp();  // C
     // D: softmax + categorical cross-entropy (lanes over the samples, wave-reduced sums)
     for (int n0 = 0; n0 < N; n0 += nt) {
         const int n = n0 + tid;
@@ -274,6 +302,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
             dpre[i] = c < NHc ? tile[n * PST + c] : 0.f;
         }
     }
+    stamp();  // D (+ copy-out)
     totals();
     // E: gradients of the small tensors (this workgroup is their only writer) and the losses
     for (int j = tid; j < NJ; j += nt) {
@@ -300,6 +329,10 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         if (a.ext_losses)                 // B3_MTL trainer: [2 nh + 4 + h] = binary accuracy of head h (training-mode outputs)
             for (int h = 0; h < nh; ++h) losses[2 * nh + 4 + h] = tot[Q_ACC + h];
     }
+    stamp();
+    if (a.stamps && tid == 0)
+        printf("heads_train_kernel N=%d (x10 ns): stage %llu  A %llu  B %llu  C %llu  D+copy %llu  E %llu\n", N, tk[1] - tk[0], tk[2] - tk[1],
+               tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
 }
 
 struct BwdArgs {
@@ -951,15 +984,27 @@ __global__ void seg_opt_kernel(const Segment *__restrict__ segs, OptArgs o, floa
 
 int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop,
                                 float *dpre, float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st) {
+    HeadsArgs ad = a;
+    ad.stamps = getenv("SMH_HEADS_STAMPS") ? 1 : 0;
     const int NHc = a.n_classes + a.n_heads * kHidden;
     const size_t lds = sizeof(float) * ((size_t)a.N * (NHc | 1) + (size_t)a.N * (a.out_dim | 1));
     // 160 KB of LDS per CU minus the kernel's static 37 KB (per-wave accumulator rows): 3-class batches up to 528 patches
-    if (lds <= 122 * 1024 && !getenv("SMH_HEADS_GLOBAL")) {
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)heads_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(heads_train_kernel<true>, dim3(1), dim3(1024), lds, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+    const bool staged = lds <= 122 * 1024 && !getenv("SMH_HEADS_GLOBAL");
+#define SMH_LAUNCH_HEADS(ST, TH)                                                                                        \
+    do {                                                                                                                \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)heads_train_kernel<ST, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)(ST ? lds : 0)));                                                        \
+        hipLaunchKernelGGL((heads_train_kernel<ST, TH>), dim3(1), dim3(TH), ST ? lds : 0, st, ad, pre, y, hp, drop, dpre, dxh,  \
+                           grad, bnstat, losses);                                                                       \
+    } while (0)
+    if (a.N <= 512) {
+        if (staged) SMH_LAUNCH_HEADS(true, 512);
+        else SMH_LAUNCH_HEADS(false, 512);
     } else {
-        hipLaunchKernelGGL(heads_train_kernel<false>, dim3(1), dim3(1024), 0, st, a, pre, y, hp, drop, dpre, dxh, grad, bnstat, losses);
+        if (staged) SMH_LAUNCH_HEADS(true, 1024);
+        else SMH_LAUNCH_HEADS(false, 1024);
     }
+#undef SMH_LAUNCH_HEADS
     return smh::launch_status("heads_train_kernel");
 }
 
