@@ -695,14 +695,17 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const int off = (tap - 1) * d;
                 const bool ok = (t + off >= 0) && (t + off < T);
                 if (tap != 1 && !__any(ok)) continue;
-                const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + q;
-                const float *wa = W1p + (size_t)(tap * C + q) * C + j;  // W1[tap][cin = 4 s8 + q][cout = j (+16)]
+                // MFMA step s8 takes input channel 8 q + s8 from lane group q (any order of k is a valid product): a lane's
+                // eight B operands are two float4 of its activation row instead of eight strided scalars
+                const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + 8 * q;
+                const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
+                const float *wa = W1p + (size_t)(tap * C + 8 * q) * C + j;  // W1[tap][cin = 8 q + s8][cout = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    float bv = src[4 * s8];
+                    float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     bv = ok ? bv : 0.f;
-                    acc0 = mfma4(wa[(4 * s8) * C], bv, acc0);
-                    acc1 = mfma4(wa[(4 * s8) * C + 16], bv, acc1);
+                    acc0 = mfma4(wa[s8 * C], bv, acc0);
+                    acc1 = mfma4(wa[s8 * C + 16], bv, acc1);
                 }
             }
             float r0[4], r1[4], mx = 0.f;
@@ -731,13 +734,14 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             // dyn[c][time] = sum_co W2[c][co] g[time][co]
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             {
-                const float *gs = G + (size_t)Rc * SX + q;
-                const float *wa = W2Tp + (size_t)q * C + j;  // W2T[co = 4 s + q][c = j (+16)]
+                const float *gs = G + (size_t)Rc * SX + 8 * q;
+                const f32x4 bA = *reinterpret_cast<const f32x4 *>(gs), bB = *reinterpret_cast<const f32x4 *>(gs + 4);
+                const float *wa = W2Tp + (size_t)(8 * q) * C + j;  // W2T[co = 8 q + s8][c = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const float bv = live ? gs[4 * s8] : 0.f;
-                    d0 = mfma4(wa[(4 * s8) * C], bv, d0);
-                    d1 = mfma4(wa[(4 * s8) * C + 16], bv, d1);
+                    const float bv = live ? (s8 < 4 ? bA[s8 & 3] : bB[s8 & 3]) : 0.f;
+                    d0 = mfma4(wa[s8 * C], bv, d0);
+                    d1 = mfma4(wa[s8 * C + 16], bv, d1);
                 }
             }
             float s1 = 0.f, cnt = 0.f;
@@ -792,14 +796,15 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const int off = (tap - 1) * d;
                 const bool ok = (t - off >= 0) && (t - off < T);
                 if (tap != 1 && !__any(ok)) continue;
-                const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + q;
-                const float *wa = W1Tp + (size_t)(tap * C + q) * C + j;  // W1T[tap][co = 4 s8 + q][c = j (+16)]
+                const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + 8 * q;
+                const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
+                const float *wa = W1Tp + (size_t)(tap * C + 8 * q) * C + j;  // W1T[tap][co = 8 q + s8][c = j (+16)]
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    float bv = src[4 * s8];
+                    float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     bv = ok ? bv : 0.f;
-                    g0 = mfma4(wa[(4 * s8) * C], bv, g0);
-                    g1 = mfma4(wa[(4 * s8) * C + 16], bv, g1);
+                    g0 = mfma4(wa[s8 * C], bv, g0);
+                    g1 = mfma4(wa[s8 * C + 16], bv, g1);
                 }
             }
             if (live) {
