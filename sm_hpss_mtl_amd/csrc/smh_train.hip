@@ -337,6 +337,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
 
 struct BwdArgs {
     int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
+    int stamps;  // tools only (SMH_BWD_STAMPS): workgroup 0 prints the time its phases took, summed over the blocks
     int use_wt;  // VALU kernel: keep transposed LDS copies of the block kernels (0 for patches so long that they do not fit)
     Offsets off;
 };
@@ -598,34 +599,37 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         G[R * SX + c] = xpre > 0.f ? acc : 0.f;
     }
 
-    auto tile_job = [&](const float *Asrc, int a_shift, int mt, const float *Bsrc, int nt_, bool ones, size_t gbase,
-                        bool bias) {
-        // D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[row][k] B[k][col], k = activation row
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: MFMA latency > issue
-        for (int s = 0; s < RPm / 4; s += 2) {
-            float av[2], bv[2];
+    // One 16 x 16 tile of a weight gradient, D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[k + a_shift][row] B[k][col] with
+    // k = activation row.  with_bias: the same pass also sums the columns of B (A = ones on a second accumulator) -- the bias
+    // gradient of that column tile; as jobs of their own the four column sums cost a third round of the eight waves.
+    // Four k steps per iteration, their eight LDS reads issued together.
+    auto tile_job = [&](const float *Asrc, int a_shift, int mt, const float *Bsrc, int nt_, size_t gbase, bool with_bias,
+                        size_t gbias) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, accb = acc;  // two chains: MFMA latency > issue
+        for (int s = 0; s < RPm / 4; s += 4) {  // RPm is a multiple of 16
+            float av[4], bv[4];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kr = 4 * (s + e) + q;
-                av[e] = 1.0f;
-                if (!ones) {
-                    const int t = kr % T;  // only rows < `rows` matter: B is zero beyond
-                    const int sr = kr + a_shift;
-                    const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
-                    av[e] = ok ? Asrc[sr * SX + 16 * mt + j] : 0.f;
-                }
-                bv[e] = (s + e < RPm / 4) ? Bsrc[kr * SX + 16 * nt_ + j] : 0.f;
+                const int t = kMG == 1 ? kr : kr % T;  // only rows < `rows` matter: B is zero beyond
+                const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
+                av[e] = ok ? Asrc[(kr + a_shift) * SX + 16 * mt + j] : 0.f;
+                bv[e] = Bsrc[kr * SX + 16 * nt_ + j];
             }
-            acc = mfma4(av[0], bv[0], acc);
-            acc2 = mfma4(av[1], bv[1], acc2);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                acc = mfma4(av[e], bv[e], acc);
+                acc2 = mfma4(av[e + 1], bv[e + 1], acc2);
+                if (with_bias) {
+                    accb = mfma4(1.0f, bv[e], accb);
+                    accb = mfma4(1.0f, bv[e + 1], accb);
+                }
+            }
         }
         acc += acc2;
-        if (bias) {
-            if (q == 0) atomicAdd(&grad[gbase + 16 * nt_ + j], acc[0]);
-        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&grad[gbase + (size_t)(16 * mt + 4 * q + r) * C + 16 * nt_ + j], acc[r]);
-        }
+        for (int r = 0; r < 4; ++r) atomicAdd(&grad[gbase + (size_t)(16 * mt + 4 * q + r) * C + 16 * nt_ + j], acc[r]);
+        if (with_bias && q == 0) atomicAdd(&grad[gbias + 16 * nt_ + j], accb[0]);
     };
 
     // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
@@ -651,6 +655,16 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
         }
     };
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+    const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0;
+    auto lap = [&](int i) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            tph[i] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (stamping) tlast = __builtin_amdgcn_s_memrealtime();
     prefetch(a.n_blocks - 1);
     // ---- residual blocks, last to first --------------------------------------------------------------------------
     for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
@@ -682,6 +696,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         const float *W1p = WLDS ? W1 : flatw + o_k1, *B1p = WLDS ? B1 : flatw + o_b1;
         const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2Tp = WLDS ? W2T : wtr + (size_t)blk * 4 * C * C + 3 * C * C;
         __syncthreads();
+        lap(0);  // barrier + inputs parked in LDS
         if (blk > 0) prefetch(blk - 1);  // overlaps with the three phases below
         // ---- phase 1: recompute, norm, dyn, norm backward -> Y, DU ---------------------------------------------
         for (int u = wave; u < units; u += nw) {
@@ -768,20 +783,19 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             *reinterpret_cast<f32x4 *>(DU + (size_t)R * SX + 16 + 4 * q) = du1;
         }
         __syncthreads();
+        lap(1);
         // ---- phase 2: weight gradients (20 tile jobs) ------------------------------------------------------------
-        for (int job = wave; job < 20; job += nw) {
+        for (int job = wave; job < 16; job += nw) {  // two rounds of the eight waves
             if (job < 4) {
-                tile_job(Y, 0, job >> 1, G, job & 1, false, o_k2, false);  // dW2[c][co]
-            } else if (job < 16) {
-                const int tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
-                tile_job(Xs, (tap - 1) * d, mt, DU, nt_, false, o_k1 + (size_t)tap * C * C, false);  // dW1[tap][c][co]
-            } else if (job < 18) {
-                tile_job(nullptr, 0, 0, G, job - 16, true, o_b2, true);   // db2[co] = sum_t g
+                const int mt = job >> 1, nt_ = job & 1;
+                tile_job(Y, 0, mt, G, nt_, o_k2, mt == 0, o_b2);  // dW2[c][co]; db2[co] = sum_t g
             } else {
-                tile_job(nullptr, 0, 0, DU, job - 18, true, o_b1, true);  // db1[co] = sum_t du
+                const int tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
+                tile_job(Xs, (tap - 1) * d, mt, DU, nt_, o_k1 + (size_t)tap * C * C, tap == 1 && mt == 0, o_b1);  // dW1; db1 = sum_t du
             }
         }
         __syncthreads();
+        lap(2);
         // ---- phase 3: g[time][c] += sum_tap sum_co W1[tap][c][co] du[time - off][co] ---------------------------------
         for (int u = wave; u < units; u += nw) {
             const int R = 16 * u + j;
@@ -814,6 +828,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         }
     }
     __syncthreads();
+    lap(3);  // (phase 3 of every block but the last lands in lap 0 of the next)
     // ---- initial Conv1D(32,1): dW0[f][c] = sum_R x[R][f] g[R][c] ; db0[c] = sum_R g[R][c] -----------------------------
     const int fmt = (a.F + 15) >> 4;
     for (int job = wave; job < fmt * 2 + 2; job += nw) {
@@ -837,6 +852,10 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             }
         }
     }
+    lap(4);
+    if (stamping)
+        printf("tcn_backward_mfma_kernel wg0 (x10 ns, summed over %d blocks): park+phase3 %llu  phase1 %llu  phase2 %llu  tail %llu  layer0 %llu\n",
+               a.n_blocks, tph[0], tph[1], tph[2], tph[3], tph[4]);
 }
 
 // wtr[blk] = [W1T[tap][co][c] | W2T[co][c]] from the canonical block kernels (long-patch variant of the kernel above)
@@ -1137,6 +1156,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     BwdArgs ba;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.use_wt = 1;
+    ba.stamps = getenv("SMH_BWD_STAMPS") ? 1 : 0;
     ba.D = m->D, ba.NH = m->NH, ba.n_classes = m->cfg.n_classes, ba.n_heads = m->n_heads, ba.off = off;
     hipLaunchKernelGGL(l2_penalty_kernel, dim3(m->n_heads * kL2Chunks), dim3(256), 0, st, ba, m->d_flat, d_losses + m->n_heads + 3,
                        t->d_l2part, reinterpret_cast<unsigned *>(t->d_l2part + kMaxHeads * kL2Chunks));
