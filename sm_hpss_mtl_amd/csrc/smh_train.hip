@@ -554,6 +554,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// combine over the four lanes that hold the same time step (l, l ^ 16, l ^ 32, l ^ 48) with gfx950's VALU lane swaps
+// instead of two ds_bpermute round trips
+template <class F>
+__device__ __forceinline__ float quad_reduce(float v, F f) {
+    const unsigned u = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = f(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    const unsigned ua = __float_as_uint(a);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return f(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+}
+
 // WLDS: the block's kernels (canonical, and transposed for the products whose k runs over the output channel) are
 // parked in LDS.  Patches longer than 128 frames (the reference's W = 249) leave no room for them next to the four
 // activation images: WLDS = false reads the canonical kernel and the bias from the weight vector itself and the
@@ -729,9 +741,9 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 r0[r] = fmaxf(acc0[r], 0.f), r1[r] = fmaxf(acc1[r], 0.f);
                 mx = fmaxf(mx, fmaxf(r0[r], r1[r]));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = quad_reduce(mx, [](float x, float y) { return fmaxf(x, y); });
             const float m = mx + kNormEps;
+            const float inv_m = __builtin_amdgcn_rcpf(m);  // the forward's own 1 / (max + eps)
             f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
             if (drop) {
                 const float *dp = drop + ((size_t)(n0 + Rc / T) * a.n_blocks + blk) * C + 4 * q;
@@ -741,8 +753,8 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             f32x4 y0, y1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                y0[r] = live ? r0[r] / m * dm0[r] : 0.f;
-                y1[r] = live ? r1[r] / m * dm1[r] : 0.f;
+                y0[r] = live ? r0[r] * inv_m * dm0[r] : 0.f;
+                y1[r] = live ? r1[r] * inv_m * dm1[r] : 0.f;
             }
             *reinterpret_cast<f32x4 *>(Y + (size_t)R * SX + 4 * q) = y0;
             *reinterpret_cast<f32x4 *>(Y + (size_t)R * SX + 16 + 4 * q) = y1;
@@ -767,13 +779,13 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 s1 = fmaf(d1[r], r1[r], s1);
                 cnt += (r0[r] == mx ? 1.f : 0.f) + (r1[r] == mx ? 1.f : 0.f);
             }
-            s1 += __shfl_xor(s1, 16), cnt += __shfl_xor(cnt, 16);
-            s1 += __shfl_xor(s1, 32), cnt += __shfl_xor(cnt, 32);
-            const float corr = s1 / (m * m) / cnt;
+            s1 = quad_reduce(s1, [](float x, float y) { return x + y; });
+            cnt = quad_reduce(cnt, [](float x, float y) { return x + y; });
+            const float corr = s1 * inv_m * inv_m / cnt;
             f32x4 du0, du1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float a0 = d0[r] / m, a1 = d1[r] / m;
+                float a0 = d0[r] * inv_m, a1 = d1[r] * inv_m;
                 if (r0[r] == mx && r0[r] > 0.f) a0 -= corr;
                 if (r1[r] == mx && r1[r] > 0.f) a1 -= corr;
                 du0[r] = (live && acc0[r] > 0.f) ? a0 : 0.f;
