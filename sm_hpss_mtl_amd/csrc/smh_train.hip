@@ -546,6 +546,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
 // The Dense-on-trunk weight gradient (a rank-N update of a D x 51 matrix) is its own kernel without atomics.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMG = 1;
+constexpr int kWS = 36;  // row stride of the weight copies in LDS (tcn_backward_mfma_kernel)
 constexpr int kMThreads = 512;
 constexpr int kMfmaMaxT = 128;   // two float4 of saved activations per thread in the register prefetch
 constexpr int kMfmaLongT = 256;  // four; kernels read from global memory (no LDS left)
@@ -582,15 +583,18 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     const int rows = g_here * T;
     const int units = RPm >> 4;
     float *Xs = sm, *G = Xs + (size_t)RPm * SX, *DU = G + (size_t)RPm * SX, *Y = DU + (size_t)RPm * SX;
-    float *W1 = Y + (size_t)RPm * SX;   // [3][32 cin][32 cout]   (canonical)
-    float *W1T = W1 + 3 * C * C;        // [3][32 cout][32 cin]
-    float *W2T = W1T + 3 * C * C;       // [32 cout][32 cin]
-    float *B1 = W2T + C * C;            // [32]
+    // A operands of the three products are rows of these copies (row = the lane's channel, eight consecutive k per lane
+    // group: two float4 per tap); rows are kWS = 36 floats apart so that 16 lanes reading 16 rows spread over the banks
+    float *W1 = Y + (size_t)RPm * SX;   // [3][32 cin][kWS: 32 cout]   (canonical)        -> phase 3
+    float *W1T = W1 + 3 * C * kWS;      // [3][32 cout][kWS: 32 cin]                      -> phase 1 (recompute)
+    float *W2 = W1T + 3 * C * kWS;      // [32 cin][kWS: 32 cout]      (canonical)        -> dyn
+    float *B1 = W2 + C * kWS;           // [32]
     float *dps = WLDS ? B1 + C : Y + (size_t)RPm * SX;  // [kMG][kPS]
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int q = lane >> 4, j = lane & 15;
 
+    const unsigned long long t_entry = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (int i = tid; i < 4 * RPm * SX; i += nt) sm[i] = 0.f;  // padded rows stay zero in every buffer
     for (int i = tid; i < g_here * kPS; i += nt) dps[i] = dpre[(size_t)n0 * kPS + i];
     __syncthreads();
@@ -667,7 +671,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
         }
     };
-    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = t_entry;
     const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0;
     auto lap = [&](int i) {
         if (stamping) {
@@ -676,7 +680,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             tlast = now;
         }
     };
-    if (stamping) tlast = __builtin_amdgcn_s_memrealtime();
+    lap(5);  // zeroing, dpre, the Dense-on-trunk backward
     prefetch(a.n_blocks - 1);
     // ---- residual blocks, last to first --------------------------------------------------------------------------
     for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
@@ -694,19 +698,20 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
                 const int i = tid + e * kMThreads;  // 3*C*C = 6 * 512
-                W1[i] = pf_w1[e];
                 const int tap = i / (C * C), c = (i / C) % C, co = i % C;
-                W1T[(tap * C + co) * C + c] = pf_w1[e];
+                W1[(tap * C + c) * kWS + co] = pf_w1[e];
+                W1T[(tap * C + co) * kWS + c] = pf_w1[e];
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = tid + e * kMThreads;  // C*C = 2 * 512
-                W2T[(i % C) * C + i / C] = pf_w2[e];
+                W2[(i / C) * kWS + i % C] = pf_w2[e];
             }
             if (tid < C) B1[tid] = pf_b1;
         }
+        constexpr int WS = WLDS ? kWS : C;  // the global copies keep the canonical stride
         const float *W1p = WLDS ? W1 : flatw + o_k1, *B1p = WLDS ? B1 : flatw + o_b1;
-        const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2Tp = WLDS ? W2T : wtr + (size_t)blk * 4 * C * C + 3 * C * C;
+        const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2p = WLDS ? W2 : flatw + o_k2;
         __syncthreads();
         lap(0);  // barrier + inputs parked in LDS
         if (blk > 0) prefetch(blk - 1);  // overlaps with the three phases below
@@ -726,13 +731,15 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 // eight B operands are two float4 of its activation row instead of eight strided scalars
                 const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
-                const float *wa = W1p + (size_t)(tap * C + 8 * q) * C + j;  // W1[tap][cin = 8 q + s8][cout = j (+16)]
+                const float *wa = W1Tp + (size_t)(tap * C + j) * WS + 8 * q;  // W1T[tap][cout = j (+16)][cin = 8 q + s8]
+                const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
+                const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     bv = ok ? bv : 0.f;
-                    acc0 = mfma4(wa[s8 * C], bv, acc0);
-                    acc1 = mfma4(wa[s8 * C + 16], bv, acc1);
+                    acc0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, acc0);
+                    acc1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, acc1);
                 }
             }
             float r0[4], r1[4], mx = 0.f;
@@ -763,12 +770,14 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             {
                 const float *gs = G + (size_t)Rc * SX + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(gs), bB = *reinterpret_cast<const f32x4 *>(gs + 4);
-                const float *wa = W2Tp + (size_t)(8 * q) * C + j;  // W2T[co = 8 q + s8][c = j (+16)]
+                const float *wa = W2p + (size_t)j * WS + 8 * q;  // W2[c = j (+16)][co = 8 q + s8]
+                const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
+                const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const float bv = live ? (s8 < 4 ? bA[s8 & 3] : bB[s8 & 3]) : 0.f;
-                    d0 = mfma4(wa[s8 * C], bv, d0);
-                    d1 = mfma4(wa[s8 * C + 16], bv, d1);
+                    d0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, d0);
+                    d1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, d1);
                 }
             }
             float s1 = 0.f, cnt = 0.f;
@@ -824,13 +833,15 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 if (tap != 1 && !__any(ok)) continue;
                 const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
-                const float *wa = W1Tp + (size_t)(tap * C + 8 * q) * C + j;  // W1T[tap][co = 8 q + s8][c = j (+16)]
+                const float *wa = W1p + (size_t)(tap * C + j) * WS + 8 * q;  // W1[tap][c = j (+16)][co = 8 q + s8]
+                const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
+                const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     bv = ok ? bv : 0.f;
-                    g0 = mfma4(wa[s8 * C], bv, g0);
-                    g1 = mfma4(wa[s8 * C + 16], bv, g1);
+                    g0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, g0);
+                    g1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, g1);
                 }
             }
             if (live) {
@@ -866,8 +877,8 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     }
     lap(4);
     if (stamping)
-        printf("tcn_backward_mfma_kernel wg0 (x10 ns, summed over %d blocks): park+phase3 %llu  phase1 %llu  phase2 %llu  tail %llu  layer0 %llu\n",
-               a.n_blocks, tph[0], tph[1], tph[2], tph[3], tph[4]);
+        printf("tcn_backward_mfma_kernel wg0 (x10 ns, summed over %d blocks): prologue %llu  park+phase3 %llu  phase1 %llu  phase2 %llu  tail %llu  layer0 %llu\n",
+               a.n_blocks, tph[5], tph[0], tph[1], tph[2], tph[3], tph[4]);
 }
 
 // wtr[blk] = [W1T[tap][co][c] | W2T[co][c]] from the canonical block kernels (long-patch variant of the kernel above)
@@ -1176,7 +1187,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (rc) return rc;
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
-    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 2 * 3 * C * C + C * C + C + kMG * kPS);
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS);
     const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS);  // kernels stay in global memory
     const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
     if ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU")) {
