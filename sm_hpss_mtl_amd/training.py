@@ -237,12 +237,26 @@ class TrainingMixin:
         self._sync_weights()
         tr = self._get_trainer(n)
         n_blocks, n_heads = self.nb_stacks * self.n_dilations, len(self.output_names) - 1
+        if isinstance(drop_tcn, str) and isinstance(drop_heads, str):
+            # both masks from ONE Bernoulli draw and one scaling (two kernels instead of eight): cached per batch size are the keep
+            # probabilities [trunk | heads] and their reciprocals
+            cache = self.__dict__.setdefault("_drop_cache", {})
+            if n not in cache:
+                n_t, n_h = n * n_blocks * 32, n * n_heads * 16
+                prob = torch.empty(n_t + n_h, dtype=torch.float32, device="cuda")
+                prob[:n_t] = 1.0 - self.dropout_rate
+                prob[n_t:] = 1.0 - HEAD_DROPOUT
+                cache.clear()
+                cache[n] = (prob, 1.0 / prob, n_t)
+            prob, scale, n_t = cache[n]
+            masks = torch.bernoulli(prob, generator=self._rng).mul_(scale)
+            drop_tcn, drop_heads = masks[:n_t].view(n, n_blocks, 32), masks[n_t:].view(n, n_heads, 16)
         if isinstance(drop_tcn, str):
             keep = 1.0 - self.dropout_rate
-            drop_tcn = (torch.rand((n, n_blocks, 32), device="cuda", generator=self._rng) < keep).float() / keep
+            drop_tcn = torch.empty((n, n_blocks, 32), device="cuda").bernoulli_(keep, generator=self._rng).div_(keep)
         if isinstance(drop_heads, str):
             keep = 1.0 - HEAD_DROPOUT
-            drop_heads = (torch.rand((n, n_heads, 16), device="cuda", generator=self._rng) < keep).float() / keep
+            drop_heads = torch.empty((n, n_heads, 16), device="cuda").bernoulli_(keep, generator=self._rng).div_(keep)
         losses = torch.empty(self._n_losses(), dtype=torch.float32, device="cuda")
         p = lambda t: None if t is None else C.c_void_p(t.contiguous().data_ptr())  # noqa: E731
         _lib.check(self.lib.smh_train_step_f32(tr, p(x), p(yt), n, p(drop_tcn), p(drop_heads), self._loss_weight_array(_only),

@@ -392,6 +392,8 @@ def test_single_head_sub_model_nadam_fine_tuning(tmp_path):
             yield x, y["M"]
     h = model.fit(gen(), steps_per_epoch=3, epochs=2, verbose=0, validation_data=gen(), validation_steps=1,
                   callbacks=[CSVLogger(str(tmp_path / "upd_log.csv"))])
-    assert set(h.history) == {"loss", "accuracy", "val_loss", "val_accuracy"} and h.history["loss"][-1] < h.history["loss"][0]
+    # (the training loss of six steps carries the dropout masks' noise; the validation loss -- inference mode, same data -- is
+    # the learning signal)
+    assert set(h.history) == {"loss", "accuracy", "val_loss", "val_accuracy"} and h.history["val_loss"][-1] < h.history["val_loss"][0]
     ev = model.evaluate(x, y["M"])
     assert len(ev) == 2 and 0.0 <= ev[1] <= 1.0
