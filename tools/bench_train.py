@@ -73,7 +73,7 @@ def main():
         res = fe.run(audio, W=W, shift=shift, out=out)
         out.update(fv=res["fv"], patches=res["patches"])
         x = res["patches"]
-        x = x + 1e-3 * torch.randn_like(x)  # noise_augmentation (Proposed_Work_Results.py:239-242; scale drawn from {5e-3, 1e-3, 5e-4, 1e-4} there)
+        x = x.add_(torch.randn_like(x), alpha=1e-3)  # noise_augmentation, in place on the patches this step produced (Proposed_Work_Results.py:239-242; scale drawn from {5e-3, 1e-3, 5e-4, 1e-4} there)
         if timed:
             ev[1].record()
         r = model.train_on_batch(x, y)  # includes the gradient all-reduce and the optimiser step
