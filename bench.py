@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-kernel HIP events on every n-th timed step (the markers of all five stages cost "
                          "about 10 us per step, 2 %% of it; the other timed steps run without them)")
+    ap.add_argument("--classes", type=int, choices=[3, 5], default=3,
+                    help="3: the headline B3_MTL (S, M, R, 3C); 5: the musan_5_class variant (S, M, N, R, 5C) of BASELINE config 5")
     ap.add_argument("--model-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = mixed-precision network (BASELINE config 5); NOT the parity path, never the default")
     ap.add_argument("--dry-run", action="store_true",
@@ -130,7 +132,7 @@ def main():
     dev = audio.device
 
     fe = Frontend(FrontendConfig(l_harm=args.l_harm, l_perc=args.l_perc))
-    model = B3MTL(n_feat=FEAT, patch_size=W_PATCH, n_classes=3, seed=0)
+    model = B3MTL(n_feat=FEAT, patch_size=W_PATCH, n_classes=args.classes, seed=0)
     hp = HotPath(fe, model, B, audio.shape[1], patch=W_PATCH, fuse_l0=not args.no_fuse_l0,
                  two_kernel_features=args.two_kernel_features, model_dtype=args.model_dtype)
     fuse_l0, want_lay = hp.fuse_l0, hp.want_layout
@@ -153,7 +155,7 @@ def main():
     parity = {"checked": False}
     gpath = os.path.join(ROOT, "tests", "golden", "bench_golden.npz")
     gkey = "logits_%dx%d" % (args.l_harm, args.l_perc)
-    if os.path.exists(gpath) and args.model_dtype == "f32":
+    if os.path.exists(gpath) and args.model_dtype == "f32" and args.classes == 3:
         g = np.load(gpath)
         n = int(g["n_clips"])
         if gkey in g and rank < g[gkey].shape[0] and B >= n:
@@ -181,6 +183,8 @@ def main():
                       "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     mfma_peak = MFMA_F32_PEAK_TFLOPS if args.model_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
     flops_model = FLOPS_MODEL - (2.0 * W_PATCH * FEAT * 32 if fuse_l0 else 0.0)  # layer 0 runs in the feature kernel when fused
+    if args.classes == 5:  # Dense-on-trunk outputs: 5 + 4 x 16 instead of 3 + 3 x 16
+        flops_model += 2.0 * W_PATCH * 32 * (69 - 51)
     tf = flops_model * B / (ms["model"] * 1e-3) / 1e12
     kernels["model"] = {"ms": round(ms["model"], 4), "bound": "mfma", "algorithmic_flops_per_clip": flops_model,
                         "achieved_TFLOPs": round(tf, 2), "frac": round(tf / mfma_peak, 4),
@@ -239,7 +243,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.model_dtype == "f32" else "f32 front end + bf16 network operands", "data": "synthetic",
             "config": {"workload": "%d x 1s@16kHz clips per GPU: STFT(400/160) -> HPSS %dx%d median + soft mask -> logmel(120) "
-                                   "-> standardise -> patch W=68 -> B3_MTL(3-class) forward" % (B, args.l_harm, args.l_perc),
+                                   "-> standardise -> patch W=68 -> B3_MTL(%d-class) forward" % (B, args.l_harm, args.l_perc, args.classes),
                        "clips_per_gpu": B, "layer0_fused_into_features": bool(fuse_l0), "harm_layout": int(hp.layout),
                        "l_harm": args.l_harm, "l_perc": args.l_perc, "patch": W_PATCH, "sharding": "per-clip, no data-path collective"},
             "roofline": roof, "kernels": kernels,
