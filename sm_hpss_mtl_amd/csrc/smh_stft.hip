@@ -251,7 +251,8 @@ __device__ __forceinline__ void dft25(float2 *x) {
     }
 }
 
-__global__ void __launch_bounds__(512)
+// (at least four waves per SIMD: 128 VGPRs -- at 129 a fourth 256-thread workgroup per CU did not fit)
+__global__ void __launch_bounds__(512, 4)
 stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window, const float2 *__restrict__ twM,
                const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe) {
     // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
@@ -387,8 +388,10 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
     // n_fft = 400 with 8-byte aligned frames: the specialised 8 x 25 kernel (SMH_STFT_GENERIC=1 forces the generic one)
     if (ctx->cfg.n_fft == 400 && ctx->M == 200 && ctx->cfg.win_length <= 400 && (ctx->cfg.hop % 2) == 0 &&
         (n_samples % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0 && !getenv("SMH_STFT_GENERIC")) {
-        // frames per workgroup: <= 16 (27 KB of LDS -> 5 workgroups = 20 waves per CU), splitting T evenly (98 -> 7 x 14)
-        int maxf = 25, nthreads = 256;
+        // frames per workgroup: <= 20 (37 KB of LDS, 128 VGPRs: FOUR 256-thread workgroups per CU), splitting T evenly (98 -> 5 x 20,
+        // the last with 18).  25 frames (45 KB: three per CU) measured 69-71 us, 20 frames 64.6; 16 and fewer leave half of phase
+        // 2's threads idle (8 items per frame) and are slower again.  tools/gpu/r2_stft_tune.sh sweeps it.
+        int maxf = 20, nthreads = 256;
         if (const char *ev = getenv("SMH_STFT_FRAMES")) sscanf(ev, "%d,%d", &maxf, &nthreads);  // tuning override
         if (nthreads != 512) nthreads = 256;
         if (maxf < 1) maxf = 1;
