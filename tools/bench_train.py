@@ -20,8 +20,8 @@ if ROOT not in sys.path:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # (a cold box runs its first steps slower: see bench.py)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step (a multiple of 3)")
     ap.add_argument("--classes", type=int, default=3, choices=[3, 5])
     ap.add_argument("--patch", type=int, default=68, help="patch width W (68; the reference's drivers also use 99 and 249)")

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=${1:-r02}
 rm -rf gpurun_out/prof/final && mkdir -p gpurun_out/prof/final
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/final/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof/final/bench_trace.log 2>&1; echo "trace rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/final/trace -- python3 bench.py --no-cpu-baseline > gpurun_out/prof/final/bench_trace.log 2>&1; echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/final/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/final/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_write.log 2>&1; echo "write rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d gpurun_out/prof/final/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/final/pmc_sq.log 2>&1; echo "sq rc=$?"
