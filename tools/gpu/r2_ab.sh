@@ -1,15 +1,13 @@
 #!/bin/bash
-# A/B of the whole bench step on one box: B3_MTL forward with the barrier schedule vs the skewed schedule
+# A/B of the whole bench step in steady state (bench.py defaults) on one box: schedule of the network's blocks, layer-0 weights of the feature kernel
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2
-for rep in 1 2 3; do
-for v in 0 1; do
-  SMH_TCN_SKEW=$v timeout -k 10 300 python bench.py --no-cpu-baseline --steps 50 --warmup 5 > gpurun_out/r2/ab_$v.json 2>/dev/null || exit 1
-  python - $v <<'PY'
-import json, sys
-d = json.load(open("gpurun_out/r2/ab_%s.json" % sys.argv[1]))
-print("skew=%s  ms_per_step %.4f  model %.1f us (frac %.4f)" % (sys.argv[1], d["ms_per_step"], d["kernels"]["model"]["ms"] * 1000, d["roofline"]["frac"]))
-PY
-done
+show() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], {k:round(v['ms']*1000,1) for k,v in d['kernels'].items() if k != 'preprocess_signal'}, d['roofline']['frac'])"; }
+for rep in 1 2; do
+timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | show "default              " || exit 1
+SMH_TCN_SKEW=0 timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | show "barrier schedule     " || exit 1
+SMH_FEAT_W0LDS=1 timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | show "layer-0 weights in LDS" || exit 1
+SMH_STFT_FRAMES=25,256 timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null | show "stft 25 frames       " || exit 1
 done
