@@ -558,19 +558,15 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 asm volatile("" : "+v"(o0), "+v"(o1));  // the sums now: the residual registers are about to be reloaded
                 const int nn = __builtin_amdgcn_readfirstlane(taken);
                 if (stamp) st[3] = __builtin_amdgcn_s_memtime();
-                const int nblk = (nn * m_units) >> 16, nu = nn - nblk * units;
+                // The operand registers are free: the next task's operands are read under the 1x1-conv products.  Unconditionally
+                // -- one straight-line region from here to the stores, which the compiler interleaves with the sixteen products;
+                // whether the reads were allowed (the task exists and its tiles stand) only decides if they count.
                 const bool have_next = nn < n_tasks;
-                // the operand registers are free: read the next task's operands under the 1x1-conv products, if its tiles stand
-                bool fetched = false;
-                if (have_next) {
-                    if (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu))) {
-                        asm volatile("" ::: "memory");
-                        issue_ops(cur, nblk, nu);
-                        fetched = true;
-                    }
-                }
+                const int nnc = min(nn, n_tasks - 1);
+                const int nblk = (nnc * m_units) >> 16, nu = nnc - nblk * units;
+                const bool fetched = have_next && (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu)));
+                issue_ops(cur, nblk, nu);
                 if (stamp) st[4] = __builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y0 = acc0[r] * inv;  // channel 4q + r
