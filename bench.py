@@ -15,7 +15,7 @@ scaling); only the timing barrier / MAX all-reduce use RCCL.  Asking for more GP
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step; per-kernel figures for every
 stage are in `kernels`: HIP events on the launch stream around every stage, recorded inside the timed region on every
-4th step (`--event-every`; five markers per step cost ~10 us).  After the timed region the logits of each rank's first
+10th step (`--event-every`; five markers per step cost ~10 us).  After the timed region the logits of each rank's first
 clips are compared with tests/golden/bench_golden.npz (CPU-oracle logits of those very clips; data only) -- a bench
 whose logits do not match the reference arithmetic fails instead of printing a number.  `cpu_baseline`
 (rank 0, N = 1 only, before the GPU is touched) times the CPU path (numpy rfft + scipy.ndimage.median_filter + the
@@ -78,7 +78,7 @@ def parse_args(argv=None):
                          "of computing the network's first 1x1 convolution inside the feature kernel")
     ap.add_argument("--two-kernel-features", action="store_true",
                     help="time-major harm + hp_feat_walk / std_patch kernels instead of the single feature kernel")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="record the per-kernel HIP events on every n-th timed step (the markers of all five stages cost "
                          "about 10 us per step, 2 %% of it; the other timed steps run without them)")
     ap.add_argument("--classes", type=int, choices=[3, 5], default=3,
