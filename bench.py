@@ -145,7 +145,8 @@ def main():
 
     # HIP events on the launch stream (torch's current stream IS the stream every kernel is launched on)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-    sampled = [k for k in range(args.steps) if k % max(1, args.event_every) == 0]
+    every = max(1, min(args.event_every, args.steps // 5))  # at least five samples when the caller asks for few steps
+    sampled = [k for k in range(args.steps) if k % every == every - 1]
     sampled_set = set(sampled)
 
     def step(k, timed):
