@@ -288,8 +288,11 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
             f += dq1 + carry;
         }
     }
+    // tw is stored by output index: tw[25 * k1 + n2] = W_200^(n2 k1), so that phase 1's lanes (n2 fastest) read consecutive
+    // entries (indexed n2 * k1 the reads were strided by k1: up to 4 lanes per bank)
     for (int i = tid; i < M; i += nthr) {
-        tw[i] = twM[i];
+        const int k1 = i / 25;
+        tw[i] = twM[(i - 25 * k1) * k1];
         win2[i] = reinterpret_cast<const float2 *>(window)[i];
     }
     for (int i = tid; i <= M; i += nthr) tw2[i] = tw2M[i];
@@ -306,7 +309,7 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         float2 *zf = Z + f * kMP400 + n2;
         zf[0] = v[0];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmul(v[k1], tw[n2 * k1]);
+        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmul(v[k1], tw[25 * k1 + n2]);
     };
     if (ahead) {
 #pragma unroll
