@@ -329,7 +329,11 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
         }
     }
     __syncthreads();
-    // phase 2: read, barrier, compute, write in place (natural order); 8 * F <= blockDim.x items
+    // phase 2: read, barrier, compute, write in place (natural order); 8 * F <= blockDim.x items.
+    // Banks: a half-wave holds 4 frames x 8 k1, float2 offsets 201 f + 25 k1 + n2.  In float2 units mod 32 the k1 terms are
+    // A = {0,25,18,11,4,29,22,15}; frames add 9 f.  A + 9 misses A, A + 18 meets it in 6 of 8 (frames f, f + 2: 2-way).  Four
+    // disjoint translates of A need pairwise differences outside A - A, e.g. {0,8,16,24} = a frame stride of 200 -- which puts
+    // phase 3's 20 frame-fastest lanes on 4 banks.  The odd stride keeps phase 3 (the longer phase) clean.
     {
         const int f = tid >> 3, k1 = tid & 7;
         const bool live = f < nf;
