@@ -478,7 +478,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         // 16) of u -- a superset of the tiles its rows +-d actually fall into (the ones in between are older still), built with
         // two 64-bit shifts instead of the eighty scalar instructions the exact set cost per task
         auto dep_mask = [&](int blk, int u) {
-            const int dmax = max(dil(blk), dil(blk > 0 ? blk - 1 : 0));
+            // (a dilation >= T reaches nothing: its side taps lie in the zero padding of every row, see issue_ops)
+            const int dr = dil(blk), dw = dil(blk > 0 ? blk - 1 : 0);
+            const int dmax = (a.tune & 4) ? max(dr, dw) : max(dr < T ? dr : 0, dw < T ? dw : 0);
             const int w = min((dmax + 15) >> 4, 31);
             const unsigned long long win = ((2ull << (2 * w)) - 1ull) << u;  // 2 w + 1 ones from bit u
             return (unsigned)(win >> w) & all_tiles;                         // ... centred on u
