@@ -173,8 +173,11 @@ __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_t
     prefetch.template slot<2 * I>();
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
+    // centre tap first, as in the skew schedule's tasks: the two schedules then add the same products in the same order and
+    // a patch's outputs do not depend on which of them its batch size selects (bit for bit)
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
+    for (int ti = 0; ti < 3; ++ti) {
+        const int tap = ti == 0 ? 1 : (ti == 1 ? 0 : 2);
         if (!any_tap[tap]) continue;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -245,7 +248,7 @@ __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int Z
 // MODE: how the 24 residual blocks are scheduled over the waves (launch_forward chooses)
 constexpr int kOneSet = 0;   // barrier per block, one weight register set read from the LDS slot at the top of the block (9..12 waves)
 constexpr int kPrefetch = 1; // barrier per block, two register sets (8 waves)
-constexpr int kSkew = 2;     // no barrier: (block, tile) tasks dealt round-robin to 8 waves, tile-level completion flags (inference)
+constexpr int kSkew = 2;     // no barrier: (block, tile) tasks taken from a counter by 8 waves, tile-level completion flags
 constexpr int kSkewSpinLimit = 1 << 22;  // polls before a wave gives up on a dependency (never reached; the grid must drain)
 
 // TRACE: tools/trace_model.py only -- s_memtime / s_memrealtime stamps into a.trace; every stamp compiles out otherwise
@@ -432,6 +435,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         BlockW w0, w1;
         load_block_lds(w0, Wb, lane, q);
         __syncthreads();  // x0, zero rows, flags
+        save_acts(xin, 0);  // (training) the input of block 0; every later slot is written by the task that produces it
         if (tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
             a.trace[4 * (2000 + blockIdx.x)] = __builtin_amdgcn_s_memtime();
             a.trace[4 * (2000 + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -447,6 +451,10 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         struct Ops {  // LDS operands of one task: the three taps' k slices, the residual row, which side taps are live
             f32x4 b[3][2], r0, r1;
             bool live0, live2;
+            // training only: the SpatialDropout1D mask of (patch, block) for this lane's channels, and this lane's row of the
+            // saved activations, ((n0 + g) * nslot) * T + t -- slot 0; -1 for the rows behind the last patch
+            f32x4 dm0, dm1;
+            int arow;
         };
         auto dil = [&](int blk) { return 1 << (blk - ((blk * m_dil) >> 16) * a.n_dil); };
         // (every index below is a multiple of four floats; said explicitly so that the reads stay ds_read_b128)
@@ -454,15 +462,31 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         auto issue_ops = [&](Ops &o, int blk, int u) {
             const int d = dil(blk);
             const int base = 16 * u, R = base + j;
-            int t = base - T * (int)__umulhi((unsigned)base, m_T) + j;  // frame index of row R inside its patch
+            int g = (int)__umulhi((unsigned)base, m_T);  // patch of the tile's first row (only the training build uses g)
+            int t = base - T * g + j;                    // frame index of row R inside its patch
             if (T >= 16) {
-                t -= t >= T ? T : 0;
+                const bool wr = t >= T;
+                t -= wr ? T : 0, g += wr ? 1 : 0;
             } else {
-                while (__any(t >= T)) t -= t >= T ? T : 0;
+                while (__any(t >= T)) {
+                    const bool wr = t >= T;
+                    t -= wr ? T : 0, g += wr ? 1 : 0;
+                }
             }
             const bool past = R >= GR;  // rows behind the last patch repeat its last row (frame T - 1)
             const int Rc = past ? GR - 1 : R;
             t = past ? T - 1 : t;
+            if constexpr (TRAIN) {
+                g = past ? g_here - 1 : g;
+                o.arow = past ? -1 : ((n0 + g) * nslot) * T + t;
+                if (drop0) {  // (uniform) L2-resident; read one task ahead like the LDS operands
+                    const float *dp = drop0 + (size_t)blk * C + (size_t)g * dstride + 4 * q;
+                    o.dm0 = *reinterpret_cast<const f32x4 *>(dp);
+                    o.dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
+                } else {
+                    o.dm0 = f32x4{1.f, 1.f, 1.f, 1.f}, o.dm1 = o.dm0;
+                }
+            }
             const bool ok0 = t >= d, ok2 = t < T - d;  // a dilation >= T leaves both side taps in the zero padding
             o.live0 = __any(ok0), o.live2 = __any(ok2);
             const int i1 = __mul24(Rc, SX) + ((blk & 1) ? xb_off : 0) + 8 * q;
@@ -558,6 +582,11 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
                 f32x4 o0 = cur.r0 + w.b2lo, o1 = cur.r1 + w.b2hi;
                 asm volatile("" : "+v"(o0), "+v"(o1));  // the sums now: the residual registers are about to be reloaded
+                int arow = 0;
+                if constexpr (TRAIN) {  // normalised and masked now: issue_ops below reloads cur (the next task's mask)
+                    acc0 = acc0 * inv * cur.dm0, acc1 = acc1 * inv * cur.dm1;
+                    arow = cur.arow;
+                }
                 const int nn = __builtin_amdgcn_readfirstlane(taken);
                 if (stamp) st[3] = __builtin_amdgcn_s_memtime();
                 // The operand registers are free: the next task's operands are read under the 1x1-conv products.  Unconditionally
@@ -571,18 +600,25 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 if (stamp) st[4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float y0 = acc0[r] * inv;  // channel 4q + r
+                    const float y0 = TRAIN ? acc0[r] : acc0[r] * inv;  // channel 4q + r
                     o0 = mfma4(w.wp[r][0], y0, o0);
                     o1 = mfma4(w.wp[r][1], y0, o1);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float y1 = acc1[r] * inv;  // channel 16 + 4q + r
+                    const float y1 = TRAIN ? acc1[r] : acc1[r] * inv;  // channel 16 + 4q + r
                     o0 = mfma4(w.wp[4 + r][0], y1, o0);
                     o1 = mfma4(w.wp[4 + r][1], y1, o1);
                 }
                 *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti, 16)) = o0;
                 *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti + 16, 16)) = o1;
+                if constexpr (TRAIN) {  // the block's output is the next block's saved input: slot blk + 1, from registers
+                    if (arow >= 0) {
+                        float *ap = tio.acts + ((size_t)arow + (size_t)(blk + 1) * T) * C + 4 * q;
+                        *reinterpret_cast<f32x4 *>(ap) = o0;
+                        *reinterpret_cast<f32x4 *>(ap + 16) = o1;
+                    }
+                }
                 pend_u = u, pend_v = blk + 1;
                 if (stamp) {
                     st[5] = __builtin_amdgcn_s_memtime();
@@ -666,7 +702,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         a.trace[4 * (2000 + blockIdx.x) + 3] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
-    save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
+    if constexpr (MODE != kSkew) save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
     if constexpr (TRAIN) __syncthreads();
     // final relu in place (xin = TCN output); optional tap to global as (N, T, 32) == Keras Flatten order
     for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
@@ -883,17 +919,24 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     // take the fewest waves in 8..12 that minimise ceil(tiles / waves): 17 tiles (4 patches of 68 frames) -> 9 waves,
     // 2 tiles each and one with 1, instead of 8 waves of which one does 3
     const int units = (std::min(a.G, N) * a.T + 15) / 16;
+    // (only without the LDS weight slots: the 9..12-wave build is held to 170 VGPRs and spills ~60 of them, which costs more
+    // than the shorter tile list saves -- training forward, 9 tiles: 134 us with 9 waves, 121 us with 8 and two register sets)
     int nwaves = 8;
-    for (int w = 9; w <= 12; ++w)
+    for (int w = 9; w <= 12 && !a.wlds; ++w)
         if ((units + w - 1) / w < (units + nwaves - 1) / nwaves) nwaves = w;
     if (const char *ev = getenv("SMH_TCN_WAVES")) nwaves = std::max(4, std::min(12, atoi(ev)));  // tuning only
     // 8 waves (two per SIMD, 256 VGPRs each): two weight register sets, the next block's weights are read behind this
     // block's products.  More waves (170 VGPRs): one set, read at the top of the block.
     bool prefetch = nwaves <= 8 && a.wlds;
     if (const char *ev = getenv("SMH_TCN_PREFETCH")) prefetch = prefetch && atoi(ev) != 0;  // tuning only
-    // inference: the skewed task schedule (8 waves, flags instead of barriers) whenever its tables fit
-    bool skew = !tio && a.wlds && units <= 32 && units >= 1;
-    if (const char *ev = getenv("SMH_TCN_SKEW")) skew = skew && atoi(ev) != 0;  // tuning only
+    // the skewed task schedule (8 waves, flags instead of barriers) whenever its tables fit -- inference and training forward
+    // It pays where the barrier schedule leaves wave slots empty AND there are enough tiles for the windows to overlap
+    // (tools/time_model_sizes.py, W = 68: 17 tiles 149 against 160 us, 13 tiles 130 / 134; 9 tiles 107 / 105.5; 5 tiles -- up to 256
+    // patches, one per workgroup -- 97 / 77: fewer tiles than waves, every task waits on the block before; W = 249, 16 tiles = two
+    // full rounds of the 8 waves: 162 / 154).  SMH_TCN_SKEW=0 / 2: never / whenever it can run (tests, tuning).
+    const bool skew_ok = a.wlds && units <= 32 && units >= 1;
+    bool skew = skew_ok && units >= 12 && 8 * ((units + 7) / 8) - units >= 3;
+    if (const char *ev = getenv("SMH_TCN_SKEW")) skew = atoi(ev) == 2 ? skew_ok : (skew && atoi(ev) != 0);
     if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
     if (skew) nwaves = std::min(nwaves, 8);
     const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
@@ -907,7 +950,8 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
                            m->d_WhA, m->d_hp, d_trunk, d_out, io);                                                     \
     } while (0)
     if (tio) {
-        if (prefetch) SMH_LAUNCH_FWD(true, kPrefetch, false);
+        if (skew) SMH_LAUNCH_FWD(true, kSkew, false);
+        else if (prefetch) SMH_LAUNCH_FWD(true, kPrefetch, false);
         else SMH_LAUNCH_FWD(true, kOneSet, false);
     } else if (a.trace) {  // tools/trace_model.py: the stamped instantiations
         if (skew) SMH_LAUNCH_FWD(false, kSkew, true);

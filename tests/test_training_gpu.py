@@ -34,7 +34,12 @@ def _flat_to_dict(model, flat):
 @pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68),
                                       (3, 3, 99),    # DAFx12...:760 -- MFMA backward, T <= 128 instantiation
                                       (3, 2, 249)])  # Proposed_Work_Results.py:724 -- MFMA backward, T <= 256 instantiation (kernels read from global memory)
-def test_gradients_and_losses_vs_oracle(ncls, N, W):
+@pytest.mark.parametrize("schedule", ["default", "skew"])
+def test_gradients_and_losses_vs_oracle(ncls, N, W, schedule, monkeypatch):
+    # schedule "skew": the training forward on the flag-synchronised task list (by default only large batches take it; it
+    # writes the saved activations and applies the SpatialDropout1D masks from inside its tasks), SMH_TCN_SKEW=2 forces it
+    if schedule == "skew":
+        monkeypatch.setenv("SMH_TCN_SKEW", "2")
     from sm_hpss_mtl_amd.model import B3MTL
     w, x, y, drop_tcn, drop_heads = _problem(ncls, N, W=W)
     lw = {"S": 0.7, "R": 1.3}
@@ -210,11 +215,13 @@ def test_data_parallel_step_equals_the_oracle_step_on_the_mean_gradient():
     assert diff > 1e-4
 
 
-@pytest.mark.parametrize("ncls,N", [(3, 510), (3, 512), (5, 510)])
-def test_gradients_and_losses_at_the_config4_batch(ncls, N):
+@pytest.mark.parametrize("ncls,N,schedule", [(3, 510, "default"), (3, 512, "default"), (5, 510, "default"), (3, 510, "skew")])
+def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatch):
     """BASELINE config 4 trains with batch 512 (3 x 170 = 510 patches for the class-balanced 3-class batch; 5 x 102 = 510
     for 5 classes).  `heads_train_kernel` is ONE workgroup whose batch reductions loop over N, the backward kernels
     accumulate over 510 workgroups with float atomics: losses and every gradient tensor at that size against the oracle."""
+    if schedule == "skew":  # two patches per workgroup on the flag-synchronised forward (see test_gradients_and_losses_vs_oracle)
+        monkeypatch.setenv("SMH_TCN_SKEW", "2")
     from sm_hpss_mtl_amd.model import B3MTL
     w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=21)
     m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls)
