@@ -548,6 +548,7 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
 constexpr int kMG = 1;
 constexpr int kWS = 36;  // row stride of the weight copies in LDS (tcn_backward_mfma_kernel)
 constexpr int kMThreads = 512;
+constexpr int kZW = 3 * SX + 4;  // zero words behind the images (tile_jobs)
 constexpr int kMfmaMaxT = 128;   // two float4 of saved activations per thread in the register prefetch
 constexpr int kMfmaLongT = 256;  // four; kernels read from global memory (no LDS left)
 
@@ -590,13 +591,16 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     float *W2 = W1T + 3 * C * kWS;      // [32 cin][kWS: 32 cout]      (canonical)        -> dyn
     float *B1 = W2 + C * kWS;           // [32]
     float *dps = WLDS ? B1 + C : Y + (size_t)RPm * SX;  // [kMG][kPS]
+    float *DM = dps + kMG * kPS;                         // [32] SpatialDropout1D mask of the current block (ones without dropout)
+    float *ZW = DM + C;                                  // [kZW] zeros: what an operand row outside the patch reads (+ up to 3 rows of offset)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;  // (wave-uniform: job and tile indices in SGPRs)
     const int q = lane >> 4, j = lane & 15;
 
     const unsigned long long t_entry = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (int i = tid; i < 4 * RPm * SX; i += nt) sm[i] = 0.f;  // padded rows stay zero in every buffer
     for (int i = tid; i < g_here * kPS; i += nt) dps[i] = dpre[(size_t)n0 * kPS + i];
+    if (tid < kZW) ZW[tid] = 0.f;
     __syncthreads();
     // ---- Dense-on-trunk backward: G = relu'(x) * (dpre @ Wh^T) ------------------------------------------------
     for (int i = tid; i < rows * C; i += nt) {
@@ -615,45 +619,105 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         G[R * SX + c] = xpre > 0.f ? acc : 0.f;
     }
 
-    // One 16 x 16 tile of a weight gradient, D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[k + a_shift][row] B[k][col] with
-    // k = activation row.  with_bias: the same pass also sums the columns of B (A = ones on a second accumulator) -- the bias
-    // gradient of that column tile; as jobs of their own the four column sums cost a third round of the eight waves.
-    // Four k steps per iteration, their eight LDS reads issued together.
-    auto tile_job = [&](const float *Asrc, int a_shift, int mt, const float *Bsrc, int nt_, size_t gbase, bool with_bias,
-                        size_t gbias) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, accb = acc;  // two chains: MFMA latency > issue
-        for (int s = 0; s < RPm / 4; s += 4) {  // RPm is a multiple of 16
-            float av[4], bv[4];
+    unsigned long long tph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = t_entry;
+    const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0;
+    auto lap = [&](int i) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            tph[i] += now - tlast;
+            tlast = now;
+        }
+    };
+    // Weight-gradient tiles: D[row = 16 mt + ..][col = 16 nt + j] = sum_k A[k + a_shift][row] B[k][col] with k = activation
+    // row.  with_bias: the same pass also sums the columns of B (A = ones on a second accumulator) -- the bias gradient of that
+    // column tile; as jobs of their own the four column sums cost a third round of the eight waves.
+    // A wave runs TWO tiles at once (16 jobs = one round of the eight waves): four k steps of both per iteration, their sixteen
+    // LDS reads issued together, four independent accumulator chains -- one tile per wave left the wave waiting for its own
+    // LDS reads and for its own previous product in turn (2.4 us per tile, two rounds: half of a block's time).
+    struct TileJob {
+        int A, B;  // offsets of the two operand images in `sm`
+        int a_shift, mt, nt;
+        unsigned gbase, gbias;
+        bool with_bias;
+    };
+    auto tile_jobs = [&](const TileJob &j0, const TileJob &j1) {
+        // One patch per workgroup: the A row of step kr is kr + a_shift, valid inside [0, T) -- ONE unsigned compare (rows
+        // kr >= T meet B = 0: every image keeps its rows behind the patch at zero, and the A row they pair with is a real
+        // row, i.e. finite).  An invalid row reads from the zero words ZW instead of skipping the read under an exec mask.
+        // Which rows a product step takes is free (any order of k is the same sum): the sixteen rows 16 m .. 16 m + 15 are
+        // taken as row 16 m + c + 4 q by lane group q in step c = 0..3, so that the four groups of a read sit 4 rows = 16 banks
+        // apart (two lanes per bank, the minimum for 64 lanes), and every address is a per-lane base that advances by 16 rows
+        // per m plus a compile-time offset.  Two steps per pipeline stage (c = 0, 1 and c = 2, 3), the reads of the next stage
+        // in flight under the products of this one.  The bias gradients (column sums of B) are VALU adds on the operands the
+        // lanes hold anyway -- as products with a ones operand they were a fifth of the phase's matrix-core time.
+        static_assert(kMG == 1, "tile_jobs: one patch per workgroup (row index == frame index)");
+        f32x4 acc[2][2];
+        float bsum[2] = {0.f, 0.f};
+        int pa[2], pb[2], ua[2];  // A / B word index of row (16 m + 4 q) for this lane; A's row index itself
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kr = 4 * (s + e) + q;
-                const int t = kMG == 1 ? kr : kr % T;  // only rows < `rows` matter: B is zero beyond
-                const bool ok = (t + a_shift >= 0) && (t + a_shift < T) && kr < rows;
-                av[e] = ok ? Asrc[(kr + a_shift) * SX + 16 * mt + j] : 0.f;
-                bv[e] = Bsrc[kr * SX + 16 * nt_ + j];
-            }
+        for (int i = 0; i < 2; ++i) {
+            const TileJob &jb = i ? j1 : j0;
+            acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ua[i] = 4 * q + jb.a_shift;
+            pa[i] = jb.A + ua[i] * SX + 16 * jb.mt + j, pb[i] = jb.B + 4 * q * SX + 16 * jb.nt + j;
+        }
+        const int zero_idx = (int)(ZW - sm);
+        auto fetch = [&](int h, int adv, float (&av)[2][2], float (&bv)[2][2]) {  // stage h of the block of 16 rows `adv` blocks ahead
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                acc = mfma4(av[e], bv[e], acc);
-                acc2 = mfma4(av[e + 1], bv[e + 1], acc2);
-                if (with_bias) {
-                    accb = mfma4(1.0f, bv[e], accb);
-                    accb = mfma4(1.0f, bv[e + 1], accb);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * h + e;
+                    const bool ok = (unsigned)(ua[i] + 16 * adv + c) < (unsigned)T;
+                    av[i][e] = sm[(ok ? pa[i] + 16 * adv * SX : zero_idx) + c * SX];
+                    bv[i][e] = sm[pb[i] + 16 * adv * SX + c * SX];
                 }
+        };
+        auto products = [&](float (&av)[2][2], float (&bv)[2][2]) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][e] = mfma4(av[i][e], bv[i][e], acc[i][e]);
+                    bsum[i] += bv[i][e];
+                }
+        };
+        float a0[2][2], b0[2][2], a1[2][2], b1[2][2];
+        fetch(0, 0, a0, b0);
+        const int M = RPm >> 4;
+        for (int m = 0; m < M; ++m) {
+            fetch(1, 0, a1, b1);
+            products(a0, b0);
+            const int adv = m + 1 < M ? 1 : 0;  // (behind the last block: the same rows again, unused)
+            fetch(0, adv, a0, b0);
+            products(a1, b1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pa[i] += 16 * SX, pb[i] += 16 * SX, ua[i] += 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const TileJob &jb = i ? j1 : j0;
+            const f32x4 v = acc[i][0] + acc[i][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&grad[jb.gbase + (unsigned)((16 * jb.mt + 4 * q + r) * C + 16 * jb.nt + j)], v[r]);
+            if (jb.with_bias) {  // (uniform) column sums: over this lane's rows, then over the four lane groups
+                const float cs = quad_reduce(bsum[i], [](float x, float y) { return x + y; });
+                if (q == 0) atomicAdd(&grad[jb.gbias + 16 * jb.nt + j], cs);
             }
         }
-        acc += acc2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&grad[gbase + (size_t)(16 * mt + 4 * q + r) * C + 16 * nt_ + j], acc[r]);
-        if (with_bias && q == 0) atomicAdd(&grad[gbias + 16 * nt_ + j], accb[0]);
     };
 
     // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
     constexpr int kPfX = (kMG * MAXT * (C / 4) + kMThreads - 1) / kMThreads;  // T <= MAXT per patch (checked on the host)
     f32x4 pf_x[kPfX];
     float pf_w1[6], pf_w2[2], pf_b1 = 0.f;
+    // the SpatialDropout1D mask of (patch, block): one patch per workgroup, so it is the same for every tile of the block --
+    // fetched with the block's other inputs and parked in LDS (DM) instead of read from L2 once per tile right before its use
+    // (an exposed L2 round trip in every tile of phase 1)
+    float pf_dm = 1.f;
     auto prefetch = [&](int blk) {
         const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+        if (kMG == 1 && drop && tid < C) pf_dm = drop[((size_t)n0 * a.n_blocks + blk) * C + tid];
 #pragma unroll
         for (int e = 0; e < kPfX; ++e) {
             const int i = tid + e * kMThreads;
@@ -669,15 +733,6 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
 #pragma unroll
             for (int e = 0; e < 2; ++e) pf_w2[e] = flatw[wo + 3 * C * C + C + tid + e * kMThreads];
             if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
-        }
-    };
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = t_entry;
-    const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0;
-    auto lap = [&](int i) {
-        if (stamping) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            tph[i] += now - tlast;
-            tlast = now;
         }
     };
     lap(5);  // zeroing, dpre, the Dense-on-trunk backward
@@ -709,6 +764,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             }
             if (tid < C) B1[tid] = pf_b1;
         }
+        if (tid < C) DM[tid] = pf_dm;
         constexpr int WS = WLDS ? kWS : C;  // the global copies keep the canonical stride
         const float *W1p = WLDS ? W1 : flatw + o_k1, *B1p = WLDS ? B1 : flatw + o_b1;
         const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2p = WLDS ? W2 : flatw + o_k2;
@@ -751,8 +807,8 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             mx = quad_reduce(mx, [](float x, float y) { return fmaxf(x, y); });
             const float m = mx + kNormEps;
             const float inv_m = __builtin_amdgcn_rcpf(m);  // the forward's own 1 / (max + eps)
-            f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
-            if (drop) {
+            f32x4 dm0 = *reinterpret_cast<const f32x4 *>(DM + 4 * q), dm1 = *reinterpret_cast<const f32x4 *>(DM + 16 + 4 * q);
+            if (kMG != 1 && drop) {
                 const float *dp = drop + ((size_t)(n0 + Rc / T) * a.n_blocks + blk) * C + 4 * q;
                 dm0 = *reinterpret_cast<const f32x4 *>(dp);
                 dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
@@ -803,18 +859,24 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             *reinterpret_cast<f32x4 *>(DU + (size_t)R * SX + 4 * q) = du0;
             *reinterpret_cast<f32x4 *>(DU + (size_t)R * SX + 16 + 4 * q) = du1;
         }
+        lap(7);  // wave 0's own tile
         __syncthreads();
         lap(1);
         // ---- phase 2: weight gradients (20 tile jobs) ------------------------------------------------------------
-        for (int job = wave; job < 16; job += nw) {  // two rounds of the eight waves
+        auto job_of = [&](int job) {  // 0..3: dW2[c][co] (db2[co] = sum_t g);  4..15: dW1[tap] (db1 = sum_t du)
+            TileJob tj;
             if (job < 4) {
-                const int mt = job >> 1, nt_ = job & 1;
-                tile_job(Y, 0, mt, G, nt_, o_k2, mt == 0, o_b2);  // dW2[c][co]; db2[co] = sum_t g
+                const int mt = job >> 1;
+                tj = TileJob{(int)(Y - sm), (int)(G - sm), 0, mt, job & 1, (unsigned)o_k2, (unsigned)o_b2, mt == 0};
             } else {
-                const int tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
-                tile_job(Xs, (tap - 1) * d, mt, DU, nt_, o_k1 + (size_t)tap * C * C, tap == 1 && mt == 0, o_b1);  // dW1; db1 = sum_t du
+                const int tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1;
+                tj = TileJob{(int)(Xs - sm), (int)(DU - sm), (tap - 1) * d, mt, (job - 4) & 1, (unsigned)(o_k1 + (size_t)tap * C * C),
+                             (unsigned)o_b1, tap == 1 && mt == 0};
             }
-        }
+            return tj;
+        };
+        for (int job = wave; job < 8; job += nw) tile_jobs(job_of(job), job_of(job + 8));  // one round of the eight waves
+        lap(6);  // wave 0's own two tiles
         __syncthreads();
         lap(2);
         // ---- phase 3: g[time][c] += sum_tap sum_co W1[tap][c][co] du[time - off][co] ---------------------------------
@@ -859,12 +921,31 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         const bool bias = job >= fmt * 2;
         const int mt = bias ? 0 : job >> 1, nt_ = bias ? job - fmt * 2 : job & 1;
         const int f = 16 * mt + j;
-        for (int s = 0; s < RPm / 4; ++s) {
-            const int kr = 4 * s + q;
-            float av = 1.0f;
-            if (!bias) av = (kr < rows && f < a.F) ? X[((size_t)n0 * T + kr) * a.F + f] : 0.f;
-            acc = mfma4(av, G[(size_t)kr * SX + 16 * nt_ + j], acc);
+        // four k steps per iteration, the next iteration's loads of X (global) in flight under this one's products: one
+        // load -> product per step left a memory round trip in every step (23 us of the kernel's 240 at one workgroup per CU)
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float *xcol = X + (size_t)n0 * T * a.F + (f < a.F ? f : 0);
+        auto fetch = [&](int s, float (&av)[4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kr = 4 * s + e + 4 * q;  // (the row order of tile_jobs: two lanes per bank on the G reads)
+                av[e] = bias ? 1.0f : ((kr < rows && f < a.F) ? xcol[(size_t)kr * a.F] : 0.f);
+            }
+        };
+        float av[4];
+        fetch(0, av);
+        for (int s = 0; s < RPm / 4; s += 4) {  // RPm is a multiple of 16
+            float an[4];
+            fetch(min(s + 4, RPm / 4 - 4), an);  // (past the end: the last rows again, unused)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                acc = mfma4(av[e], G[(size_t)(4 * s + e + 4 * q) * SX + 16 * nt_ + j], acc);
+                acc2 = mfma4(av[e + 1], G[(size_t)(4 * s + e + 1 + 4 * q) * SX + 16 * nt_ + j], acc2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = an[e];
         }
+        acc += acc2;
         if (bias) {
             if (q == 0) atomicAdd(&grad[a.off.w0_b + 16 * nt_ + j], acc[0]);
         } else {
@@ -878,8 +959,25 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     lap(4);
     if (stamping)
         printf("tcn_backward_mfma_kernel wg0 (x10 ns, summed over %d blocks): prologue %llu  park+phase3 %llu  phase1 %llu  phase2 %llu  tail %llu  layer0 %llu\n",
-               a.n_blocks, tph[5], tph[0], tph[1], tph[2], tph[3], tph[4]);
+               a.n_blocks, tph[5], tph[0], tph[1] + tph[7], tph[2] + tph[6], tph[3], tph[4]);
+    if (stamping) printf("   wave 0's own share: phase 1 tile %llu, phase 2 tiles %llu (the rest of each phase is its wait at the barrier)\n", tph[7], tph[6]);
 }
+
+}  // namespace
+
+// tools / tests: workgroups of the MFMA backward kernel (T <= 128 instantiation) that fit one CU at patch size T -- two at the
+// reference's T = 68 (126 VGPRs, 79 KB of LDS); one register class more and it is one, 345 -> 445 us per 510-patch step
+extern "C" int smh_internal_bwd_residency(int T) {
+    const int RPm = ((kMG * T + 15) / 16) * 16;
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS + C + kZW);
+    auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) return -1;
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kMThreads, lds_m) != hipSuccess) return -1;
+    return nb;
+}
+
+namespace {
 
 // wtr[blk] = [W1T[tap][co][c] | W2T[co][c]] from the canonical block kernels (long-patch variant of the kernel above)
 __global__ void transpose_block_weights_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ wtr) {
@@ -1187,8 +1285,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (rc) return rc;
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
-    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS);
-    const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS);  // kernels stay in global memory
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS + C + kZW);
+    const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS + C + kZW);  // kernels stay in global memory
     const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
     if ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU")) {
         const dim3 grid((N + kMG - 1) / kMG);

@@ -196,7 +196,10 @@ def test_data_parallel_step_equals_the_oracle_step_on_the_mean_gradient():
     clipped = 0
     for k, v in wd.items():
         delta = np.abs(v - w0[k]).max()  # 0 for the Dense(16) biases: a bias in front of BatchNorm has no gradient
-        assert np.abs(res[0][k] - v).max() <= 2e-3 * delta + 1e-7, (k, np.abs(res[0][k] - v).max(), delta)
+        # (2e-7: a few float32 ulps of the weights themselves -- two `w += v` roundings plus the order of the float atomics that
+        # accumulate the gradient; tcn/initial_conv/kernel has measured 5.97e-7 against an update of 2.5e-4.  A wrong 1/world
+        # factor or clip order moves a weight by half of delta.)
+        assert np.abs(res[0][k] - v).max() <= 2e-3 * delta + 2e-7, (k, np.abs(res[0][k] - v).max(), delta)
         if not k.endswith(tr.TRAINABLE_SKIP) and np.sqrt(np.sum(gmean[k] ** 2)) > 1.0:
             clipped += 1
     assert clipped >= 1  # the problem does exercise clipnorm (else clip-before-average could not be told apart)
@@ -404,3 +407,16 @@ def test_single_head_sub_model_nadam_fine_tuning(tmp_path):
     assert set(h.history) == {"loss", "accuracy", "val_loss", "val_accuracy"} and h.history["val_loss"][-1] < h.history["val_loss"][0]
     ev = model.evaluate(x, y["M"])
     assert len(ev) == 2 and 0.0 <= ev[1] <= 1.0
+
+
+def test_backward_kernel_residency():
+    """The MFMA backward kernel keeps TWO workgroups per CU at the reference's patch size (126 VGPRs, 79 KB of LDS):
+    a 510-patch step is one round of the chip.  One register class more and it is two rounds (345 -> 445 us) without any parity
+    test noticing."""
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    lib = _lib.require_gpu()
+    f = lib.smh_internal_bwd_residency
+    f.restype = C.c_int
+    f.argtypes = [C.c_int]
+    assert f(68) == 2
