@@ -785,15 +785,15 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 if (tap != 1 && !__any(ok)) continue;
                 // MFMA step s8 takes input channel 8 q + s8 from lane group q (any order of k is a valid product): a lane's
                 // eight B operands are two float4 of its activation row instead of eight strided scalars
-                const float *src = Xs + (size_t)(ok ? Rc + off : Rc) * SX + 8 * q;
+                // (a row outside the patch reads the zero words: one select on the address instead of one per operand)
+                const float *src = (ok ? Xs + (size_t)(Rc + off) * SX : ZW) + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
                 const float *wa = W1Tp + (size_t)(tap * C + j) * WS + 8 * q;  // W1T[tap][cout = j (+16)][cin = 8 q + s8]
                 const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
                 const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
-                    bv = ok ? bv : 0.f;
+                    const float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     acc0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, acc0);
                     acc1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, acc1);
                 }
@@ -824,14 +824,14 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             // dyn[c][time] = sum_co W2[c][co] g[time][co]
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             {
-                const float *gs = G + (size_t)Rc * SX + 8 * q;
+                const float *gs = G + (size_t)R * SX + 8 * q;  // (rows behind the patch are zero in G)
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(gs), bB = *reinterpret_cast<const f32x4 *>(gs + 4);
                 const float *wa = W2p + (size_t)j * WS + 8 * q;  // W2[c = j (+16)][co = 8 q + s8]
                 const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
                 const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const float bv = live ? (s8 < 4 ? bA[s8 & 3] : bB[s8 & 3]) : 0.f;
+                    const float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     d0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, d0);
                     d1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, d1);
                 }
@@ -893,15 +893,14 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const int off = (tap - 1) * d;
                 const bool ok = (t - off >= 0) && (t - off < T);
                 if (tap != 1 && !__any(ok)) continue;
-                const float *src = DU + (size_t)(ok ? Rc - off : Rc) * SX + 8 * q;
+                const float *src = (ok ? DU + (size_t)(Rc - off) * SX : ZW) + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
                 const float *wa = W1p + (size_t)(tap * C + j) * WS + 8 * q;  // W1[tap][c = j (+16)][co = 8 q + s8]
                 const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
                 const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
-                    bv = ok ? bv : 0.f;
+                    const float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
                     g0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, g0);
                     g1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, g1);
                 }
