@@ -995,7 +995,7 @@ __global__ void transpose_block_weights_kernel(BwdArgs a, const float *__restric
 // (grid.y, kDwhSlice patches each) hit contiguous addresses -- one lane per row of the matrix was 17x slower.
 constexpr int kDwhSlice = 16;
 __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const float *__restrict__ dpre,
-                           float *__restrict__ grad) {
+                           float *__restrict__ grad, int slice) {
     const int grp = blockIdx.z;
     const int ocount = grp == 0 ? a.n_classes : kHidden;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1003,13 +1003,62 @@ __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const floa
     const int k = i / ocount, o = i - k * ocount;
     const int nslot = a.n_blocks + 1;
     const int o0 = grp == 0 ? 0 : a.n_classes + (grp - 1) * kHidden;
-    const int b0 = blockIdx.y * kDwhSlice, b1 = min(a.N, b0 + kDwhSlice);
+    const int b0 = blockIdx.y * slice, b1 = min(a.N, b0 + slice);
     float acc = 0.f;
     for (int b = b0; b < b1; ++b) {
         const float fl = fmaxf(acts[((size_t)b * nslot + a.n_blocks) * a.D + k], 0.f);
         acc = fmaf(fl, dpre[(size_t)b * kPS + o0 + o], acc);
     }
     atomicAdd(grad + (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + i, acc);
+}
+
+// The same rank-N update on the matrix cores: dWh (D x 51) = relu(X)^T (D x N) . dpre (N x 51).  One wave = one 16 x 16 tile
+// (16 trunk units k x the 16 outputs of one Dense(16) head, or the n_classes outputs of '3C') over one slice of the batch;
+// A[i = k][kk = patch] are 64-byte runs of the saved trunk, B[kk = patch][j = output] 64-byte runs of dpre; eight product steps
+// (32 patches) per iteration with their sixteen loads in flight together; batch slices combined by float atomics as above.
+// 36 us -> see DESIGN 7 (the one-thread-per-element kernel is a dependent chain of N / slice loads + FMAs per thread).
+constexpr int kDwhSplit = 8;  // batch slices (grid.z)
+__global__ void __launch_bounds__(256) dwh_mfma_kernel(BwdArgs a, const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                       float *__restrict__ grad) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int k0 = (blockIdx.x * 4 + wave) * 16;
+    if (k0 >= a.D) return;
+    const int grp = blockIdx.y;  // 0: '3C', 1 + h: head h
+    const int ocount = grp == 0 ? a.n_classes : kHidden;
+    const int col0 = grp == 0 ? 0 : a.n_classes + (grp - 1) * kHidden;
+    const int per = (((a.N + kDwhSplit - 1) / kDwhSplit) + 3) & ~3;  // patches per slice, a multiple of the 4 of a product step
+    const int b0 = blockIdx.z * per, b1 = min(a.N, b0 + per);
+    if (b0 >= b1) return;
+    const int nslot = a.n_blocks + 1;
+    const float *ap = acts + (size_t)a.n_blocks * a.D + k0 + i;  // + b * nslot * D
+    const size_t astride = (size_t)nslot * a.D;
+    const bool col_ok = i < ocount;
+    const float *bp = dpre + col0 + (col_ok ? i : 0);  // + b * kPS
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int b = b0; b < b1; b += 32) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int bb = b + 4 * u + kq;
+            const bool ok = bb < b1;
+            const int bc = ok ? bb : b0;
+            const float x = ap[(size_t)bc * astride], d = bp[(size_t)bc * kPS];
+            av[u] = ok ? fmaxf(x, 0.f) : 0.f;
+            bv[u] = (ok && col_ok) ? d : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = mfma4(av[u], bv[u], acc0);
+            acc1 = mfma4(av[u + 1], bv[u + 1], acc1);
+        }
+    }
+    acc0 += acc1;
+    if (col_ok) {
+        float *g = grad + (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + (size_t)(k0 + 4 * kq) * ocount + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(g + (size_t)r * ocount, acc0[r]);
+    }
 }
 
 // l2(0.01) penalty of the Dense(16) kernels (the term Keras adds to the reported total loss), from the weights the
@@ -1303,9 +1352,14 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
         }
         rc = smh::launch_status("tcn_backward_mfma_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(dwh_kernel, dim3((ba.D * kHidden + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice, 1 + ba.n_heads),
-                           dim3(256), 0, st, ba, t->d_acts, t->d_dpre, t->d_grad);
-        return smh::launch_status("dwh_kernel");
+        if (getenv("SMH_DWH_VALU")) {  // the one-thread-per-element kernel (a second implementation for the tests)
+            hipLaunchKernelGGL(dwh_kernel, dim3((ba.D * kHidden + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice, 1 + ba.n_heads),
+                               dim3(256), 0, st, ba, t->d_acts, t->d_dpre, t->d_grad, kDwhSlice);
+            return smh::launch_status("dwh_kernel");
+        }
+        hipLaunchKernelGGL(dwh_mfma_kernel, dim3((ba.D / 16 + 3) / 4, 1 + ba.n_heads, kDwhSplit), dim3(256), 0, st, ba, t->d_acts,
+                           t->d_dpre, t->d_grad);
+        return smh::launch_status("dwh_mfma_kernel");
     }
     const int RP = kBG * ba.T;
     size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);

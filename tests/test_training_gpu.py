@@ -34,12 +34,14 @@ def _flat_to_dict(model, flat):
 @pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68),
                                       (3, 3, 99),    # DAFx12...:760 -- MFMA backward, T <= 128 instantiation
                                       (3, 2, 249)])  # Proposed_Work_Results.py:724 -- MFMA backward, T <= 256 instantiation (kernels read from global memory)
-@pytest.mark.parametrize("schedule", ["default", "skew"])
+@pytest.mark.parametrize("schedule", ["default", "skew", "dwh_valu"])
 def test_gradients_and_losses_vs_oracle(ncls, N, W, schedule, monkeypatch):
     # schedule "skew": the training forward on the flag-synchronised task list (by default only large batches take it; it
     # writes the saved activations and applies the SpatialDropout1D masks from inside its tasks), SMH_TCN_SKEW=2 forces it
     if schedule == "skew":
         monkeypatch.setenv("SMH_TCN_SKEW", "2")
+    if schedule == "dwh_valu":  # the Dense-on-trunk weight gradient by the one-thread-per-element kernel instead of the MFMA one
+        monkeypatch.setenv("SMH_DWH_VALU", "1")
     from sm_hpss_mtl_amd.model import B3MTL
     w, x, y, drop_tcn, drop_heads = _problem(ncls, N, W=W)
     lw = {"S": 0.7, "R": 1.3}
