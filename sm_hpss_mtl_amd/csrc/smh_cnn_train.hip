@@ -754,7 +754,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
     for (const Layer &L : m->layers)
         if (L.op == kConv) maxN = std::max(maxN, (size_t)L.C);
     alloc(&t->d_ones, maxN), alloc(&t->d_zeros, maxN);
-    alloc(&t->d_pre, NB * kPS), alloc(&t->d_dpre, NB * kPS), alloc(&t->d_dxh, NB * kPS);
+    alloc(&t->d_pre, NB * kPS), alloc(&t->d_dpre, NB * kPS), alloc(&t->d_dxh, NB * kPS + 4);  // + the heads kernel's ticket
     alloc(&t->d_scratch, NB * (size_t)m->out_dim);
     // ONE bucket [gradient (n_params) | BatchNorm batch statistics (bstat)]: what data-parallel training all-reduces
     alloc(&t->d_grad, m->n_params + bstat), alloc(&t->d_s1, m->n_params), alloc(&t->d_s2, m->n_params);
@@ -839,6 +839,7 @@ extern "C" int smh_cnn_trainer_create(smh_cnn *m, int max_batch, smh_cnn_trainer
         if (e == hipSuccess) e = hipMemset(t->d_s2, 0, m->n_params * sizeof(float));
         if (e == hipSuccess) e = hipMemset(t->d_grad, 0, (m->n_params + t->bstat_floats) * sizeof(float));
         if (e == hipSuccess) e = hipMemset(t->d_zeros, 0, maxN * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(t->d_dxh + NB * kPS, 0, 4 * sizeof(float));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(fill_kernel, dim3(nblk(maxN)), dim3(256), 0, 0, t->d_ones, maxN, 1.0f);
             e = hipDeviceSynchronize();
@@ -979,7 +980,8 @@ extern "C" int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, cons
     rc = smh::launch_status("heads_pre_kernel");
     if (rc) return rc;
     rc = smh_tcn::launch_heads_train(ha, t->d_pre, d_y, F, d_drop_heads, t->d_dpre, t->d_dxh, t->d_grad,
-                                     t->d_bstat + t->head_bstat, d_losses, st);
+                                     t->d_bstat + t->head_bstat, d_losses,
+                                     reinterpret_cast<unsigned *>(t->d_dxh + (size_t)t->max_batch * kPS), st);
     if (rc) return rc;
     hipLaunchKernelGGL(l2_partial_kernel, dim3(t->nseg), dim3(256), 0, st, (const Seg *)t->d_segs, F, t->d_l2part);
     hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(1024), 0, st, (const double *)t->d_l2part, t->nseg, d_losses + m->n_heads + 3);

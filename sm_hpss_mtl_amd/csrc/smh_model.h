@@ -50,8 +50,9 @@ struct HeadsArgs {
     int ext_losses;               // 1: `losses` has 3 n_heads + 4 floats and gets the per-head binary accuracies at [2 nh + 4 + h]
     int stamps;                   // tools only (SMH_HEADS_STAMPS): thread 0 prints the phase durations (100 MHz ticks)
 };
+// ticket: one zero-initialised device word the kernel's workgroups count themselves on (left at zero again)
 int launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop, float *dpre,
-                       float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st);
+                       float *dxh, float *grad, float *bnstat, float *losses, unsigned *ticket, hipStream_t st);
 
 }  // namespace smh_tcn
 

@@ -63,7 +63,12 @@ __device__ __forceinline__ void wave_add(float *row, int q, float v, bool first 
 enum { Q_SUM1 = 0, Q_SUM2 = 64, Q_DGAMMA = 128, Q_DBETA = 192, Q_DBIAS = 256, Q_DWO = 320, Q_DBO = Q_DWO + smh_tcn::kMaxHeads * smh_tcn::kHidden * 3,
        Q_LOSS = Q_DBO + smh_tcn::kMaxHeads * 3, Q_DB3 = Q_LOSS + smh_tcn::kMaxHeads + 2, Q_ACC = Q_DB3 + 8, kQ = Q_ACC + smh_tcn::kMaxHeads };
 
-// Single workgroup: the batch-statistics part of the network is tiny (N x 51 values).  Every reduction over the
+// One workgroup per output head (blockIdx.x < n_heads: the Dense(16) -> BN -> relu -> Dropout -> Dense head of that index;
+// blockIdx.x == n_heads: the '3C' softmax): the heads share nothing but the total loss -- BatchNorm's batch statistics are per
+// hidden unit -- so each stages, reduces and writes only its own 16 (or n_classes) columns, and the last workgroup to arrive
+// (ticket) adds the weighted losses in a fixed order.  As ONE workgroup running the heads one after the other this kernel was
+// 79 us of a 510-patch step on an otherwise idle chip.
+// Inside a workgroup: the batch-statistics part of the network is tiny (N x 51 values).  Every reduction over the
 // batch is spread over the lanes (16 lanes per hidden unit for the statistics; one head at a time with wave-level
 // sums for the gradients of the small tensors) -- a thread looping over the whole batch was 60 % of this kernel.
 // STAGED (the batch fits: N <= kHeadsStageMax): `pre` and the targets are copied to LDS once, coalesced and all in flight,
@@ -77,7 +82,7 @@ template <bool STAGED, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__restrict__ y, const float *__restrict__ hp,
                    const float *__restrict__ drop, float *__restrict__ dpre, float *__restrict__ dxh,
-                   float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses) {
+                   float *__restrict__ grad, float *__restrict__ bnstat, float *__restrict__ losses, unsigned *__restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) float stage[];
     __shared__ float s_mean[64], s_inv[64];
     __shared__ float red[16][kQ], tot[kQ];  // per-wave accumulator rows (blockDim.x <= 1024), their totals
@@ -85,7 +90,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     float *row = red[tid >> 6];
     unsigned long long tk[8];
     int ntk = 0;
-    auto stamp = [&]() { if (a.stamps && tid == 0 && ntk < 8) tk[ntk++] = __builtin_amdgcn_s_memrealtime(); };
+    auto stamp = [&]() { if (a.stamps && tid == 0 && blockIdx.x == 0 && ntk < 8) tk[ntk++] = __builtin_amdgcn_s_memrealtime(); };
     stamp();
     auto totals = [&]() {  // every wave's row -> tot, in wave order; called by all threads between barriers
         __syncthreads();
@@ -97,13 +102,17 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         __syncthreads();
     };
     const int N = a.N, ncls = a.n_classes, nh = a.n_heads, NJ = nh * kHidden, NHc = ncls + NJ;
+    const int role = blockIdx.x;  // < nh: head `role`; == nh: the '3C' softmax
+    const bool is_cls = role == nh;
+    const int j_lo = is_cls ? 0 : role * kHidden, j_hi = is_cls ? 0 : j_lo + kHidden;  // this workgroup's hidden units
+    const int c_lo = is_cls ? 0 : ncls + j_lo, c_n = is_cls ? ncls : kHidden;           // ... and its columns of pre / dpre
     const int PST = NHc | 1, YST = a.out_dim | 1;  // odd row strides: lane = sample reads are conflict-free
     float *tile = stage, *ty = stage + (size_t)(STAGED ? N : 0) * PST;
     auto P = [&](int n, int c) -> float { return STAGED ? tile[n * PST + c] : pre[(size_t)n * kPS + c]; };
     auto Y = [&](int n, int c) -> float { return STAGED ? ty[n * YST + c] : y[(size_t)n * a.out_dim + c]; };
     if constexpr (STAGED) {
-        for (int i = tid; i < N * NHc; i += nt) {
-            const int n = i / NHc, c = i - n * NHc;
+        for (int i = tid; i < N * c_n; i += nt) {
+            const int n = i / c_n, c = c_lo + (i - n * c_n);
             tile[n * PST + c] = pre[(size_t)n * kPS + c];
         }
         for (int i = tid; i < N * a.out_dim; i += nt) {
@@ -115,9 +124,9 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     if constexpr (STAGED) __syncthreads();
     stamp();  // staged
     // A: batch statistics of every hidden unit (population variance, two passes): 16 lanes per unit
-    for (int j0 = 0; j0 < NJ; j0 += nt >> 4) {
+    for (int j0 = j_lo; j0 < j_hi; j0 += nt >> 4) {
         const int j = j0 + (tid >> 4), sub = tid & 15;
-        const bool on = j < NJ;
+        const bool on = j < j_hi;
         float s = 0.f;
         if (on)
             for (int n = sub; n < N; n += 16) s += P(n, ncls + j);
@@ -145,7 +154,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     stamp();  // A
     // B: one head at a time, lanes over the samples: forward through BN / relu / dropout / output Dense, loss,
     // gradients; sums over the batch are wave-reduced before they touch LDS
-    for (int h = 0; h < nh; ++h) {
+    for (int h = role; h < (is_cls ? role : role + 1); ++h) {
         const float *ph = hp + a.hp_off[h];
         int col = 0;
         for (int k = 0; k < h; ++k) col += a.head_odim[k];
@@ -220,7 +229,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     }
     totals();  // dbeta / dgamma of every unit; the BatchNorm backward's sums follow from them: dxhat = gamma dbn, so
     // sum_n dxhat = gamma dbeta and sum_n dxhat xhat = gamma dgamma (32 fewer wave sums per head)
-    for (int j = tid; j < NJ; j += nt) {
+    for (int j = j_lo + tid; j < j_hi; j += nt) {
         const float gm = hp[a.hp_off[j / kHidden] + (j % kHidden)];
         tot[Q_SUM1 + j] = gm * tot[Q_DBETA + j];
         tot[Q_SUM2 + j] = gm * tot[Q_DGAMMA + j];
@@ -231,18 +240,19 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         // C: BN backward to the Dense(16) pre-activations, lanes over the samples of one unit; d replaces pre in the tile
         const int NR = ((N + 63) >> 6) << 6;  // whole waves per unit: the wave sum below needs every lane
         constexpr int kCI = 8;  // dxh values requested ahead per thread (one L2 trip per eight iterations instead of one each)
-        for (int it0 = tid; it0 < NJ * NR; it0 += kCI * nt) {
+        const int NJr = j_hi - j_lo;
+        for (int it0 = tid; it0 < NJr * NR; it0 += kCI * nt) {
             float dv[kCI];
 #pragma unroll
             for (int e = 0; e < kCI; ++e) {
-                const int it = it0 + e * nt, j = it / NR, n = it - j * NR;
-                dv[e] = (it < NJ * NR && n < N) ? dxh[(size_t)j * N + n] : 0.f;
+                const int it = it0 + e * nt, jr = it / NR, n = it - jr * NR, j = j_lo + jr;
+                dv[e] = (it < NJr * NR && n < N) ? dxh[(size_t)j * N + n] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < kCI; ++e) {
                 const int it = it0 + e * nt;
-                if (it >= NJ * NR) break;  // wave-uniform (NR and nt are multiples of 64)
-                const int j = it / NR, n = it - j * NR;
+                if (it >= NJr * NR) break;  // wave-uniform (NR and nt are multiples of 64)
+                const int jr = it / NR, n = it - jr * NR, j = j_lo + jr;
                 float d = 0.f;
                 if (n < N) {
                     const float xhat = (tile[n * PST + ncls + j] - s_mean[j]) * s_inv[j];
@@ -254,8 +264,9 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         }
     } else {
         // C: BN backward to the Dense(16) pre-activations
-        for (int it = tid; it < N * NJ; it += nt) {
-            const int n = it / NJ, j = it - n * NJ;
+        const int NJr = j_hi - j_lo;
+        for (int it = tid; it < N * NJr; it += nt) {
+            const int n = it / NJr, j = j_lo + (it - n * NJr);
             const float xhat = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
             const float d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)n * kPS + j] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
             dpre[(size_t)n * kPS + ncls + j] = d;
@@ -264,7 +275,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     }
     stamp();  // C
     // D: softmax + categorical cross-entropy (lanes over the samples, wave-reduced sums)
-    for (int n0 = 0; n0 < N; n0 += nt) {
+    for (int n0 = 0; n0 < (is_cls ? N : 0); n0 += nt) {
         const int n = n0 + tid;
         const bool on = n < N;
         const int nc = on ? n : N - 1;
@@ -297,15 +308,20 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     }
     if constexpr (STAGED) {
         __syncthreads();
-        for (int i = tid; i < N * kPS; i += nt) {  // d loss / d pre leaves in one coalesced copy
-            const int n = i / kPS, c = i - n * kPS;
-            dpre[i] = c < NHc ? tile[n * PST + c] : 0.f;
+        for (int i = tid; i < N * c_n; i += nt) {  // d loss / d pre: this workgroup's columns (64-byte runs per sample for a head)
+            const int n = i / c_n, c = c_lo + (i - n * c_n);
+            dpre[(size_t)n * kPS + c] = tile[n * PST + c];
         }
+        if (is_cls)  // the padding columns behind the last head
+            for (int i = tid; i < N * (kPS - NHc); i += nt) {
+                const int n = i / (kPS - NHc), c = NHc + (i - n * (kPS - NHc));
+                dpre[(size_t)n * kPS + c] = 0.f;
+            }
     }
     stamp();  // D (+ copy-out)
     totals();
     // E: gradients of the small tensors (this workgroup is their only writer) and the losses
-    for (int j = tid; j < NJ; j += nt) {
+    for (int j = j_lo + tid; j < j_hi; j += nt) {
         const int h = j / kHidden, i = j % kHidden;
         float *gh = grad + a.goff_head[h] + (size_t)a.D * kHidden;  // after the dense kernel
         gh[i] = tot[Q_DBIAS + j];
@@ -315,23 +331,27 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
         for (int c = 0; c < od; ++c) gh[16 + 64 + i * od + c] = tot[Q_DWO + j * 3 + c];
         if (i < od) gh[16 + 64 + kHidden * od + i] = tot[Q_DBO + h * 3 + i];
     }
-    if (tid < ncls) grad[a.goff_c3b + tid] = tot[Q_DB3 + tid];
+    if (is_cls && tid < ncls) grad[a.goff_c3b + tid] = tot[Q_DB3 + tid];
     if (tid == 0) {
-        float total = 0.f;
-        for (int h = 0; h < nh; ++h) {
-            losses[h] = tot[Q_LOSS + h];
-            total += a.lw[h] * tot[Q_LOSS + h];
+        if (is_cls) {
+            losses[nh] = tot[Q_LOSS + nh];
+            losses[nh + 2] = tot[Q_LOSS + nh + 1];  // 3C accuracy
+        } else {
+            losses[role] = tot[Q_LOSS + role];
+            if (a.ext_losses) losses[2 * nh + 4 + role] = tot[Q_ACC + role];  // B3_MTL trainer: binary accuracy of head h (training-mode outputs)
         }
-        losses[nh] = tot[Q_LOSS + nh];
-        total += a.lw[nh] * tot[Q_LOSS + nh];
-        losses[nh + 1] = total;           // without the l2 term (losses[nh + 3], l2_penalty_kernel)
-        losses[nh + 2] = tot[Q_LOSS + nh + 1];  // 3C accuracy
-        if (a.ext_losses)                 // B3_MTL trainer: [2 nh + 4 + h] = binary accuracy of head h (training-mode outputs)
-            for (int h = 0; h < nh; ++h) losses[2 * nh + 4 + h] = tot[Q_ACC + h];
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {  // the last head to finish: the weighted total, in head order
+            __threadfence();
+            float total = 0.f;
+            for (int h = 0; h <= nh; ++h) total += a.lw[h] * __builtin_nontemporal_load(losses + h);
+            losses[nh + 1] = total;  // without the l2 term (losses[nh + 3], l2_penalty_kernel)
+            *ticket = 0;             // ready for the next step (stream order)
+        }
     }
     stamp();
-    if (a.stamps && tid == 0)
-        printf("heads_train_kernel N=%d (x10 ns): stage %llu  A %llu  B %llu  C %llu  D+copy %llu  E %llu\n", N, tk[1] - tk[0], tk[2] - tk[1],
+    if (a.stamps && tid == 0 && blockIdx.x == 0)
+        printf("heads_train_kernel (head 0) N=%d (x10 ns): stage %llu  A %llu  B %llu  C %llu  D+copy %llu  E %llu\n", N, tk[1] - tk[0], tk[2] - tk[1],
                tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
 }
 
@@ -1176,7 +1196,8 @@ __global__ void seg_opt_kernel(const Segment *__restrict__ segs, OptArgs o, floa
 }  // namespace
 
 int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const float *y, const float *hp, const float *drop,
-                                float *dpre, float *dxh, float *grad, float *bnstat, float *losses, hipStream_t st) {
+                                float *dpre, float *dxh, float *grad, float *bnstat, float *losses, unsigned *ticket,
+                                hipStream_t st) {
     HeadsArgs ad = a;
     ad.stamps = getenv("SMH_HEADS_STAMPS") ? 1 : 0;
     const int NHc = a.n_classes + a.n_heads * kHidden;
@@ -1187,8 +1208,8 @@ int smh_tcn::launch_heads_train(const HeadsArgs &a, const float *pre, const floa
     do {                                                                                                                \
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)heads_train_kernel<ST, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           (int)(ST ? lds : 0)));                                                        \
-        hipLaunchKernelGGL((heads_train_kernel<ST, TH>), dim3(1), dim3(TH), ST ? lds : 0, st, ad, pre, y, hp, drop, dpre, dxh,  \
-                           grad, bnstat, losses);                                                                       \
+        hipLaunchKernelGGL((heads_train_kernel<ST, TH>), dim3(a.n_heads + 1), dim3(TH), ST ? lds : 0, st, ad, pre, y, hp, drop, \
+                           dpre, dxh, grad, bnstat, losses, ticket);                                                    \
     } while (0)
     if (a.N <= 512) {
         if (staged) SMH_LAUNCH_HEADS(true, 512);
@@ -1259,7 +1280,8 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     hipError_t e = hipMalloc((void **)&t->d_acts, nact * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_pre, (size_t)max_batch * kPS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_dpre, (size_t)max_batch * kPS * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_dxh, (size_t)max_batch * kPS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_dxh, ((size_t)max_batch * kPS + 4) * sizeof(float));  // + the heads kernel's ticket
+    if (e == hipSuccess) e = hipMemset(t->d_dxh + (size_t)max_batch * kPS, 0, 4 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_grad, (m->n_params + kMaxHeads * 32) * sizeof(float));
     if (e == hipSuccess) t->d_bnstat = t->d_grad + m->n_params;
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_vel, m->n_params * sizeof(float));
@@ -1320,7 +1342,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
         ha.hp_off[i] = hpo;
         hpo += 4 * kHidden + (size_t)kHidden * m->head_odim[i] + m->head_odim[i];
     }
-    rc = launch_heads_train(ha, t->d_pre, d_y, m->d_hp, d_drop_heads, t->d_dpre, t->d_dxh, t->d_grad, t->d_bnstat, d_losses, st);
+    rc = launch_heads_train(ha, t->d_pre, d_y, m->d_hp, d_drop_heads, t->d_dpre, t->d_dxh, t->d_grad, t->d_bnstat, d_losses,
+                            reinterpret_cast<unsigned *>(t->d_dxh + (size_t)t->max_batch * kPS), st);
     if (rc) return rc;
     BwdArgs ba;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
