@@ -35,6 +35,8 @@ struct TrainIO {
     float *acts;            // (N, n_blocks + 1, T, 32): input of every block, then the pre-relu TCN output
     const float *drop_tcn;  // (N, n_blocks, 32) SpatialDropout1D masks (0 or 1/(1-rate)), or nullptr
     float *pre;             // (N, kPS): Dense-on-trunk outputs incl. bias (3C logits | head Dense(16)s)
+    float *upre;            // (N, n_blocks, T, 32): every block's dilated-conv output incl. bias, before the relu -- the gates of
+                            // the backward's relu / channel-max normalisation (it used to recompute them: 48 products per tile)
 };
 
 // heads_train_kernel (smh_train.hip): batch-statistics BN, Dropout, the four losses and d loss / d pre for the '3C'

@@ -148,7 +148,9 @@ struct WeightPrefetch {  // behind the last block the reads still run (they fetc
 template <bool TRAIN, int I, class PF>
 __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_taps, int T, int GR, int ZR, int R, int t, int g,
                                              int q, const float *__restrict__ xin, float *__restrict__ xout,
-                                             const float *__restrict__ drop, int dstride, const PF &prefetch) {
+                                             const float *__restrict__ drop, int dstride, float *__restrict__ ub, int ustride,
+                                             const PF &prefetch) {
+    // ub (training): this block's slice of the saved dilated-conv outputs for the workgroup's first patch, patch stride ustride
     const int Rc = min(R, GR - 1);
     // all LDS operands of the tile up front: 3 taps x 8 channels of this lane's k slice (k index = tap*32 + c; MFMA
     // step s8 of a tap takes channel c = 8 q + s8 from lane group q, so a lane's eight B operands are contiguous in
@@ -190,6 +192,13 @@ __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_t
     __builtin_amdgcn_sched_barrier(0);
     prefetch.template slot<2 * I + 1>();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TRAIN) {
+        if (ub && R < GR) {
+            const unsigned uo = (unsigned)(g * ustride + t * C + 4 * q);  // 32-bit offset from a uniform base
+            *reinterpret_cast<f32x4 *>(ub + uo) = acc0;
+            *reinterpret_cast<f32x4 *>(ub + uo + 16) = acc1;
+        }
+    }
     // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
     float mx = 0.f;
 #pragma unroll
@@ -203,9 +212,9 @@ __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_t
     f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
     if constexpr (TRAIN) {
         if (drop) {
-            const float *dp = drop + (size_t)g * dstride + 4 * q;
-            dm0 = *reinterpret_cast<const f32x4 *>(dp);
-            dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
+            const unsigned dofs = (unsigned)(g * dstride + 4 * q);  // 32-bit offset from a uniform base
+            dm0 = *reinterpret_cast<const f32x4 *>(drop + dofs);
+            dm1 = *reinterpret_cast<const f32x4 *>(drop + dofs + 16);
         }
     }
     // 1x1 conv on the normalised activations + bias + residual, all from registers
@@ -231,11 +240,13 @@ __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_t
 template <bool TRAIN, class PF>
 __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
                                           const float *__restrict__ xin, float *__restrict__ xout,
-                                          const float *__restrict__ drop, int dstride, PF prefetch) {
+                                          const float *__restrict__ drop, int dstride, float *__restrict__ ub, int ustride,
+                                          PF prefetch) {
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
     auto tile = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        tile_compute<TRAIN, i>(w, d, side_taps, T, GR, ZR, ti.R[i], ti.t[i], ti.g[i], q, xin, xout, drop, dstride, prefetch);
+        tile_compute<TRAIN, i>(w, d, side_taps, T, GR, ZR, ti.R[i], ti.t[i], ti.g[i], q, xin, xout, drop, dstride, ub, ustride,
+                               prefetch);
     };
     static_assert(kMaxTiles == 4, "tile list below");
     if (ti.n > 0) tile(std::integral_constant<int, 0>{});  // wave-uniform
@@ -398,10 +409,12 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     };
     const float *drop0 = TRAIN && tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * a.n_blocks * C : nullptr;
     const int dstride = a.n_blocks * C;
+    const int ustride = a.n_blocks * T * C;
+    float *ub0 = TRAIN && tio.upre ? tio.upre + (size_t)n0 * ustride : nullptr;
     auto one_block = [&](int blk, BlockW &w, auto prefetch) {
         save_acts(xin, blk);
         run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, ZR, ti, q, xin, xout, drop0 ? drop0 + (size_t)blk * C : nullptr, dstride,
-                         prefetch);
+                         ub0 ? ub0 + (size_t)blk * T * C : nullptr, ustride, prefetch);
         float *tmp = xin;
         xin = xout;
         xout = tmp;
@@ -454,7 +467,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             // training only: the SpatialDropout1D mask of (patch, block) for this lane's channels, and this lane's row of the
             // saved activations, ((n0 + g) * nslot) * T + t -- slot 0; -1 for the rows behind the last patch
             f32x4 dm0, dm1;
-            int arow;
+            int arow, urow;  // urow: ((n0 + g) * n_blocks) * T + t, this lane's row of the saved dilated-conv outputs (block 0)
         };
         auto dil = [&](int blk) { return 1 << (blk - ((blk * m_dil) >> 16) * a.n_dil); };
         // (every index below is a multiple of four floats; said explicitly so that the reads stay ds_read_b128)
@@ -479,6 +492,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             if constexpr (TRAIN) {
                 g = past ? g_here - 1 : g;
                 o.arow = past ? -1 : ((n0 + g) * nslot) * T + t;
+                o.urow = ((n0 + g) * a.n_blocks) * T + t;
                 if (drop0) {  // (uniform) L2-resident; read one task ahead like the LDS operands
                     const float *dp = drop0 + (size_t)blk * C + (size_t)g * dstride + 4 * q;
                     o.dm0 = *reinterpret_cast<const f32x4 *>(dp);
@@ -565,6 +579,13 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 half_tap(1, 1);
                 if (cur.live0) half_tap(0, 0), half_tap(0, 1);
                 if (cur.live2) half_tap(2, 0), half_tap(2, 1);
+                if constexpr (TRAIN) {  // the dilated-conv output before the relu: the backward's gates
+                    if (tio.upre && cur.arow >= 0) {
+                        float *up = tio.upre + ((size_t)cur.urow + (size_t)blk * T) * C + 4 * q;
+                        *reinterpret_cast<f32x4 *>(up) = acc0;
+                        *reinterpret_cast<f32x4 *>(up + 16) = acc1;
+                    }
+                }
                 // take the next task and sample the flags; both are judged behind the epilogue
                 if (stamp) st[2] = __builtin_amdgcn_s_memtime();
                 int taken = 0;
@@ -940,7 +961,7 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
     if (skew) nwaves = std::min(nwaves, 8);
     const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
-    TrainIO io{nullptr, nullptr, nullptr};
+    TrainIO io{nullptr, nullptr, nullptr, nullptr};
     if (tio) io = *tio;
 #define SMH_LAUNCH_FWD(TR, MD, TC)                                                                                      \
     do {                                                                                                                \

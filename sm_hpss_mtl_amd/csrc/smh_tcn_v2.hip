@@ -187,7 +187,7 @@ b3mtl_forward_v2_kernel(TcnArgs a, const float *__restrict__ X, const float *__r
             const int R = i >> 3, c4 = (i & 7) * 4;
             *reinterpret_cast<f32x4 *>(trunk + ((size_t)n0 * T + R) * C + c4) = *reinterpret_cast<const f32x4 *>(xa + (size_t)R * SX + c4);
         }
-    TrainIO none{nullptr, nullptr, nullptr};
+    TrainIO none{nullptr, nullptr, nullptr, nullptr};
     dense_and_heads<false>(a, xa, ya, WhA, hp, out, none, n0, g_here);
 }
 

@@ -553,16 +553,15 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
 // MFMA form of the backward pass (the default).  One workgroup = kMG patches (rows = kMG*T activations rows of 32
 // channels in LDS, stride SX), 8 waves.  Per residual block, last to first, with the block input x re-read from the
 // activations the TRAIN forward saved:
-//   1. per 16-row tile (one wave each): u = conv_d(x) + b1 recomputed with the forward's transposed products
-//      D[channel][time] (48 MFMA), relu / channel-max norm -> y (to LDS), dyn = W2 . g as D[c][time] (16 MFMA, g from
-//      LDS as B operand), the norm / relu backward in registers (same lane owns the same channels of u and dyn)
-//      -> du (to LDS);
+//   1. per 16-row tile (one wave each): u = conv_d(x) + b1 as the forward saved it (TrainIO::upre, register-prefetched in
+//      accumulator layout; it used to be recomputed: 48 MFMA per tile), relu / channel-max norm -> y (to LDS), dyn = W2 . g
+//      as D[c][time] (16 MFMA, g from LDS as B operand), the norm / relu backward in registers (same lane owns the same
+//      channels of u and dyn) -> du (to LDS);
 //   2. weight gradients as 16 x 16 output tiles with K = rows: dW2[c][co] = sum_t y[t][c] g[t][co],
-//      dW1[tap][c][co] = sum_t x[t+off][c] du[t][co], biases as products with a ones operand; 20 tile jobs over the
-//      8 waves, results added to the global gradient with hardware float atomics;
+//      dW1[tap][c][co] = sum_t x[t+off][c] du[t][co], the bias gradients as column sums on the VALU; 16 tiles, two per wave,
+//      results added to the global gradient with hardware float atomics;
 //   3. per tile: g += sum_tap W1[tap] . du[t - off] (48 MFMA), in place.
-// A operands come from LDS copies of the block's canonical kernels (W1 for the recompute, W1T / W2T = input-channel
-// minor for the two transposed products: conflict-free for lanes that run over the row index).
+// A operands come from LDS copies of the block's canonical kernels (rows = the lane's channel, stride kWS).
 // The Dense-on-trunk weight gradient (a rank-N update of a D x 51 matrix) is its own kernel without atomics.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMG = 1;
@@ -588,15 +587,13 @@ __device__ __forceinline__ float quad_reduce(float v, F f) {
     return f(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
 }
 
-// WLDS: the block's kernels (canonical, and transposed for the products whose k runs over the output channel) are
-// parked in LDS.  Patches longer than 128 frames (the reference's W = 249) leave no room for them next to the four
-// activation images: WLDS = false reads the canonical kernel and the bias from the weight vector itself and the
-// transposed copies from `wtr` ([block][W1T 3*32*32 | W2T 32*32], written by transpose_block_weights_kernel per step).
+// WLDS: the block's canonical kernels are parked in LDS.  Patches longer than 128 frames (the reference's W = 249) leave no room
+// for them next to the four activation images: WLDS = false reads them from the weight vector itself.
 template <bool WLDS, int MAXT>
 __global__ void __launch_bounds__(kMThreads)
 tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw,
                          const float *__restrict__ acts, const float *__restrict__ drop, const float *__restrict__ dpre,
-                         float *__restrict__ grad, int RPm, const float *__restrict__ wtr) {
+                         float *__restrict__ grad, int RPm, const float *__restrict__ upre) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int T = a.T, nslot = a.n_blocks + 1;
     const int n0 = blockIdx.x * kMG;
@@ -607,10 +604,8 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     // A operands of the three products are rows of these copies (row = the lane's channel, eight consecutive k per lane
     // group: two float4 per tap); rows are kWS = 36 floats apart so that 16 lanes reading 16 rows spread over the banks
     float *W1 = Y + (size_t)RPm * SX;   // [3][32 cin][kWS: 32 cout]   (canonical)        -> phase 3
-    float *W1T = W1 + 3 * C * kWS;      // [3][32 cout][kWS: 32 cin]                      -> phase 1 (recompute)
-    float *W2 = W1T + 3 * C * kWS;      // [32 cin][kWS: 32 cout]      (canonical)        -> dyn
-    float *B1 = W2 + C * kWS;           // [32]
-    float *dps = WLDS ? B1 + C : Y + (size_t)RPm * SX;  // [kMG][kPS]
+    float *W2 = W1 + 3 * C * kWS;       // [32 cin][kWS: 32 cout]      (canonical)        -> dyn
+    float *dps = WLDS ? W2 + C * kWS : Y + (size_t)RPm * SX;  // [kMG][kPS]
     float *DM = dps + kMG * kPS;                         // [32] SpatialDropout1D mask of the current block (ones without dropout)
     float *ZW = DM + C;                                  // [kZW] zeros: what an operand row outside the patch reads (+ up to 3 rows of offset)
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -730,7 +725,12 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     // register prefetch of a block's inputs: saved activations (rows x 8 float4) and its two kernels + bias
     constexpr int kPfX = (kMG * MAXT * (C / 4) + kMThreads - 1) / kMThreads;  // T <= MAXT per patch (checked on the host)
     f32x4 pf_x[kPfX];
-    float pf_w1[6], pf_w2[2], pf_b1 = 0.f;
+    float pf_w1[6], pf_w2[2];
+    // the block's dilated-conv outputs before the relu, as the training forward saved them (TrainIO::upre), for this wave's
+    // tiles in accumulator layout: the gates of the relu / channel-max backward.  (They used to be recomputed from the block
+    // input: 48 products per tile, a transposed LDS copy of the kernel and half of phase 1's time.)
+    constexpr int kTPW = (MAXT / 16 + 7) / 8;  // tiles per wave: 1 up to 128 frames, 2 up to 256
+    f32x4 pf_u[kTPW][2];
     // the SpatialDropout1D mask of (patch, block): one patch per workgroup, so it is the same for every tile of the block --
     // fetched with the block's other inputs and parked in LDS (DM) instead of read from L2 once per tile right before its use
     // (an exposed L2 round trip in every tile of phase 1)
@@ -752,11 +752,25 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             for (int e = 0; e < 6; ++e) pf_w1[e] = flatw[wo + tid + e * kMThreads];
 #pragma unroll
             for (int e = 0; e < 2; ++e) pf_w2[e] = flatw[wo + 3 * C * C + C + tid + e * kMThreads];
-            if (tid < C) pf_b1 = flatw[wo + 3 * C * C + tid];
+        }
+    };
+    // requested in front of phase 3 of the block before (not with the block's other inputs: eight more registers across the
+    // weight-gradient phase would cost the second workgroup per CU)
+    auto prefetch_u = [&](int blk) {
+#pragma unroll
+        for (int i = 0; i < kTPW; ++i) {
+            const int R = 16 * (wave + i * 8) + j;  // (8 waves)
+            pf_u[i][0] = pf_u[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (R < rows) {
+                const float *up = upre + (((size_t)n0 * a.n_blocks + blk) * T + R) * C + 4 * q;  // one patch per workgroup: row == frame
+                pf_u[i][0] = *reinterpret_cast<const f32x4 *>(up);
+                pf_u[i][1] = *reinterpret_cast<const f32x4 *>(up + 16);
+            }
         }
     };
     lap(5);  // zeroing, dpre, the Dense-on-trunk backward
     prefetch(a.n_blocks - 1);
+    prefetch_u(a.n_blocks - 1);
     // ---- residual blocks, last to first --------------------------------------------------------------------------
     for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
         const int d = 1 << (blk % a.n_dil);
@@ -775,49 +789,30 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const int i = tid + e * kMThreads;  // 3*C*C = 6 * 512
                 const int tap = i / (C * C), c = (i / C) % C, co = i % C;
                 W1[(tap * C + c) * kWS + co] = pf_w1[e];
-                W1T[(tap * C + co) * kWS + c] = pf_w1[e];
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = tid + e * kMThreads;  // C*C = 2 * 512
                 W2[(i / C) * kWS + i % C] = pf_w2[e];
             }
-            if (tid < C) B1[tid] = pf_b1;
         }
         if (tid < C) DM[tid] = pf_dm;
         constexpr int WS = WLDS ? kWS : C;  // the global copies keep the canonical stride
-        const float *W1p = WLDS ? W1 : flatw + o_k1, *B1p = WLDS ? B1 : flatw + o_b1;
-        const float *W1Tp = WLDS ? W1T : wtr + (size_t)blk * 4 * C * C, *W2p = WLDS ? W2 : flatw + o_k2;
+        const float *W1p = WLDS ? W1 : flatw + o_k1, *W2p = WLDS ? W2 : flatw + o_k2;
         __syncthreads();
         lap(0);  // barrier + inputs parked in LDS
+        f32x4 cur_u[kTPW][2];
+#pragma unroll
+        for (int i = 0; i < kTPW; ++i) cur_u[i][0] = pf_u[i][0], cur_u[i][1] = pf_u[i][1];
         if (blk > 0) prefetch(blk - 1);  // overlaps with the three phases below
-        // ---- phase 1: recompute, norm, dyn, norm backward -> Y, DU ---------------------------------------------
-        for (int u = wave; u < units; u += nw) {
+        // ---- phase 1: norm (from the saved conv outputs), dyn, norm backward -> Y, DU ------------------------------
+#pragma unroll
+        for (int ti = 0; ti < kTPW; ++ti) {
+            const int u = wave + ti * 8;
+            if (u >= units) break;
             const int R = 16 * u + j;
             const bool live = R < rows;
-            const int Rc = min(R, rows - 1);
-            const int t = Rc % T;
-            f32x4 acc0 = *reinterpret_cast<const f32x4 *>(B1p + 4 * q), acc1 = *reinterpret_cast<const f32x4 *>(B1p + 16 + 4 * q);
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                const int off = (tap - 1) * d;
-                const bool ok = (t + off >= 0) && (t + off < T);
-                if (tap != 1 && !__any(ok)) continue;
-                // MFMA step s8 takes input channel 8 q + s8 from lane group q (any order of k is a valid product): a lane's
-                // eight B operands are two float4 of its activation row instead of eight strided scalars
-                // (a row outside the patch reads the zero words: one select on the address instead of one per operand)
-                const float *src = (ok ? Xs + (size_t)(Rc + off) * SX : ZW) + 8 * q;
-                const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
-                const float *wa = W1Tp + (size_t)(tap * C + j) * WS + 8 * q;  // W1T[tap][cout = j (+16)][cin = 8 q + s8]
-                const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
-                const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    const float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
-                    acc0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, acc0);
-                    acc1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, acc1);
-                }
-            }
+            const f32x4 acc0 = cur_u[ti][0], acc1 = cur_u[ti][1];
             float r0[4], r1[4], mx = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -828,11 +823,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             const float m = mx + kNormEps;
             const float inv_m = __builtin_amdgcn_rcpf(m);  // the forward's own 1 / (max + eps)
             f32x4 dm0 = *reinterpret_cast<const f32x4 *>(DM + 4 * q), dm1 = *reinterpret_cast<const f32x4 *>(DM + 16 + 4 * q);
-            if (kMG != 1 && drop) {
-                const float *dp = drop + ((size_t)(n0 + Rc / T) * a.n_blocks + blk) * C + 4 * q;
-                dm0 = *reinterpret_cast<const f32x4 *>(dp);
-                dm1 = *reinterpret_cast<const f32x4 *>(dp + 16);
-            }
+            static_assert(kMG == 1, "one patch per workgroup: one dropout mask per block (DM)");
             f32x4 y0, y1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -899,6 +890,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         lap(6);  // wave 0's own two tiles
         __syncthreads();
         lap(2);
+        if (blk > 0) prefetch_u(blk - 1);
         // ---- phase 3: g[time][c] += sum_tap sum_co W1[tap][c][co] du[time - off][co] ---------------------------------
         for (int u = wave; u < units; u += nw) {
             const int R = 16 * u + j;
@@ -988,7 +980,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
 // reference's T = 68 (126 VGPRs, 79 KB of LDS); one register class more and it is one, 345 -> 445 us per 510-patch step
 extern "C" int smh_internal_bwd_residency(int T) {
     const int RPm = ((kMG * T + 15) / 16) * 16;
-    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS + C + kZW);
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 4 * C * kWS + kMG * kPS + C + kZW);
     auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) return -1;
     int nb = -1;
@@ -997,18 +989,6 @@ extern "C" int smh_internal_bwd_residency(int T) {
 }
 
 namespace {
-
-// wtr[blk] = [W1T[tap][co][c] | W2T[co][c]] from the canonical block kernels (long-patch variant of the kernel above)
-__global__ void transpose_block_weights_kernel(BwdArgs a, const float *__restrict__ flatw, float *__restrict__ wtr) {
-    const int blk = blockIdx.x;
-    const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
-    float *dst = wtr + (size_t)blk * 4 * C * C;
-    for (int i = threadIdx.x; i < 3 * C * C; i += blockDim.x) {
-        const int tap = i / (C * C), c = (i / C) % C, co = i % C;
-        dst[(tap * C + co) * C + c] = flatw[wo + i];
-    }
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) dst[3 * C * C + (i % C) * C + i / C] = flatw[wo + 3 * C * C + C + i];
-}
 
 // dWh[k][o] = sum_b relu(x_b)[k] dpre[b][o] for the '3C' kernel (grid.z = 0) and the Dense(16) kernel of every head
 // (grid.z = 1 + h): one thread per element (k, o), o fastest, so the float atomics that combine the batch slices
@@ -1229,7 +1209,8 @@ struct smh_trainer {
     // ONE bucket [gradient (n_params) | BatchNorm batch statistics (kMaxHeads * 32)]: what data-parallel training all-reduces
     float *d_grad = nullptr, *d_bnstat = nullptr;
     float *d_vel = nullptr, *d_s2 = nullptr;  // optimiser state: momentum / first moment, second moment
-    float *d_sumsq = nullptr, *d_scratch_out = nullptr, *d_wtr = nullptr;
+    float *d_sumsq = nullptr, *d_scratch_out = nullptr;
+    float *d_upre = nullptr;  // (max_batch, n_blocks, T, 32): TrainIO::upre
     double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
     Segment *d_segs = nullptr;
     long step = 0;             // optimiser steps taken (Adam / Nadam bias corrections)
@@ -1288,7 +1269,7 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_s2, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_sumsq, segs.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_scratch_out, (size_t)max_batch * m->out_dim * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->d_wtr, (size_t)m->n_blocks * 4 * C * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_upre, (size_t)max_batch * m->n_blocks * m->cfg.patch_size * C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_l2part, (kMaxHeads * kL2Chunks + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMemset(t->d_l2part, 0, (kMaxHeads * kL2Chunks + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_segs, segs.size() * sizeof(Segment));
@@ -1306,7 +1287,7 @@ extern "C" int smh_trainer_create(smh_model *m, int max_batch, smh_trainer **out
 
 extern "C" void smh_trainer_destroy(smh_trainer *t) {
     if (!t) return;
-    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_s2, t->d_sumsq, t->d_scratch_out, t->d_wtr})
+    for (float *p : {t->d_acts, t->d_pre, t->d_dpre, t->d_dxh, t->d_grad, t->d_vel, t->d_s2, t->d_sumsq, t->d_scratch_out, t->d_upre})
         (void)hipFree(p);
     (void)hipFree(t->d_segs);
     (void)hipFree(t->d_l2part);
@@ -1322,7 +1303,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     smh_model *m = t->m;
     hipStream_t st = (hipStream_t)stream;
     SMH_CHECK_HIP(hipMemsetAsync(t->d_grad, 0, m->n_params * sizeof(float), st));
-    TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre};
+    TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre, t->d_upre};
     int rc = launch_forward(m, d_x, N, t->d_scratch_out, nullptr, &tio, st);
     if (rc) return rc;
     const Offsets off = offsets(m);
@@ -1356,7 +1337,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (rc) return rc;
     // MFMA backward (default); SMH_TRAIN_VALU=1 keeps the scalar reference kernel
     const int RPm = ((kMG * ba.T + 15) / 16) * 16;
-    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 7 * C * kWS + C + kMG * kPS + C + kZW);
+    const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 4 * C * kWS + kMG * kPS + C + kZW);
     const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS + C + kZW);  // kernels stay in global memory
     const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
     if ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU")) {
@@ -1365,13 +1346,12 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
             auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
             hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,
-                               RPm, (const float *)nullptr);
+                               RPm, (const float *)t->d_upre);
         } else {
-            hipLaunchKernelGGL(transpose_block_weights_kernel, dim3(m->n_blocks), dim3(256), 0, st, ba, (const float *)m->d_flat, t->d_wtr);
             auto kern = tcn_backward_mfma_kernel<false, kMfmaLongT>;
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
             hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_long, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre,
-                               t->d_grad, RPm, (const float *)t->d_wtr);
+                               t->d_grad, RPm, (const float *)t->d_upre);
         }
         rc = smh::launch_status("tcn_backward_mfma_kernel");
         if (rc) return rc;

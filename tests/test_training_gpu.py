@@ -248,10 +248,11 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
         scale = max(np.abs(gref).max(), 1e-6)
         # 510 x 68 rows x 24 blocks: a handful of rows sit within float32 rounding of a relu gate or of a tie of the channel
         # maximum and take the other branch than the float64 oracle.  Tensor-level agreement (relative L2) stays tight; single
-        # elements may move by a few 1e-3 of the tensor's maximum (measured: <= 2.6e-3).
+        # elements may move by a few 1e-3 of the tensor's maximum (measured: <= 2.6e-3 when the backward recomputed the gates with
+        # its own summation order, <= 5.5e-3 now that it takes the gates the float32 forward actually used, TrainIO::upre).
         rel_l2 = np.linalg.norm(gg - gref) / max(np.linalg.norm(gref), 1e-12)
         assert rel_l2 <= 2e-3 or name.endswith("/dense/bias"), (name, rel_l2)
-        assert np.abs(gg - gref).max() <= 5e-3 * scale + (2e-5 if name.endswith("/dense/bias") else 1e-6), (name, np.abs(gg - gref).max(), scale)
+        assert np.abs(gg - gref).max() <= 1e-2 * scale + (2e-5 if name.endswith("/dense/bias") else 1e-6), (name, np.abs(gg - gref).max(), scale)
     # batch statistics handed to the moving averages (behind the gradient in the data-parallel bucket)
     bn = m._bucket_tensor()[m.count_params():].cpu().numpy()
     for hi, h in enumerate(heads):
