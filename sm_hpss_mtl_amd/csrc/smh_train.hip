@@ -668,24 +668,27 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         static_assert(kMG == 1, "tile_jobs: one patch per workgroup (row index == frame index)");
         f32x4 acc[2][2];
         float bsum[2] = {0.f, 0.f};
-        int pa[2], pb[2], ua[2];  // A / B word index of row (16 m + 4 q) for this lane; A's row index itself
+        // j0 is always an unshifted tile (dW2 or the centre tap): its operand rows 0 .. RPm - 1 all exist (zero behind the patch)
+        // and need no validity test; byte offsets throughout (a select on a word index costs a shift per read on top).
+        int pa[2], pb[2], ua[2];  // A / B byte offset of row (16 m + 4 q) for this lane; A's row index itself
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const TileJob &jb = i ? j1 : j0;
             acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             ua[i] = 4 * q + jb.a_shift;
-            pa[i] = jb.A + ua[i] * SX + 16 * jb.mt + j, pb[i] = jb.B + 4 * q * SX + 16 * jb.nt + j;
+            pa[i] = 4 * (jb.A + ua[i] * SX + 16 * jb.mt + j), pb[i] = 4 * (jb.B + 4 * q * SX + 16 * jb.nt + j);
         }
-        const int zero_idx = (int)(ZW - sm);
+        const int zero_off = 4 * (int)(ZW - sm);
+        auto lds_at = [&](int byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sm) + byte_off); };
         auto fetch = [&](int h, int adv, float (&av)[2][2], float (&bv)[2][2]) {  // stage h of the block of 16 rows `adv` blocks ahead
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int c = 2 * h + e;
-                    const bool ok = (unsigned)(ua[i] + 16 * adv + c) < (unsigned)T;
-                    av[i][e] = sm[(ok ? pa[i] + 16 * adv * SX : zero_idx) + c * SX];
-                    bv[i][e] = sm[pb[i] + 16 * adv * SX + c * SX];
+                    const bool ok = i == 0 || (unsigned)(ua[i] + 16 * adv + c) < (unsigned)T;
+                    av[i][e] = lds_at((ok ? pa[i] + 64 * adv * SX : zero_off) + 4 * c * SX);
+                    bv[i][e] = lds_at(pb[i] + 64 * adv * SX + 4 * c * SX);
                 }
         };
         auto products = [&](float (&av)[2][2], float (&bv)[2][2]) {
@@ -707,7 +710,7 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             fetch(0, adv, a0, b0);
             products(a1, b1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) pa[i] += 16 * SX, pb[i] += 16 * SX, ua[i] += 16;
+            for (int i = 0; i < 2; ++i) pa[i] += 64 * SX, pb[i] += 64 * SX, ua[i] += 16;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -886,7 +889,8 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             }
             return tj;
         };
-        for (int job = wave; job < 8; job += nw) tile_jobs(job_of(job), job_of(job + 8));  // one round of the eight waves
+        // one round of the eight waves, an unshifted tile (dW2, centre tap) first and a side-tap tile second in every pair
+        for (int w = wave; w < 8; w += nw) tile_jobs(job_of(w < 4 ? w : w + 4), job_of(w < 4 ? w + 4 : w + 8));
         lap(6);  // wave 0's own two tiles
         __syncthreads();
         lap(2);
