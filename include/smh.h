@@ -30,6 +30,7 @@ extern "C" {
 #define SMH_E_INVALID (-1)   /* bad argument / unsupported size            */
 #define SMH_E_HIP (-2)       /* HIP runtime error (launch, alloc, no GPU)  */
 #define SMH_E_WORKSPACE (-3) /* caller workspace too small                 */
+#define SMH_E_DEVICE (-4)    /* a kernel reported through the object's device error word that its outputs are not results */
 
 #define SMH_MAX_MEDIAN 63 /* largest supported (odd) median window        */
 
@@ -239,6 +240,12 @@ int smh_model_out_dim(const smh_model *m);
  * [S | M | (N) | R | 3C-softmax] per row, i.e. model.predict's list concatenated on axis 1
  * (Proposed_Work_Results.py:520,586).  d_trunk (N, W, nb_filters) optional TCN output tap.      */
 int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
+/* Error contract of the stream-ordered forwards (SURVEY 8(b) "Errors": the reference raises; a launch cannot).  Every
+ * smh_model_forward_* only enqueues work, so a condition a kernel meets on the device -- today one: a wave of the barrier-free
+ * block schedule whose dependency did not arrive within its bounded spin -- is recorded in the model's device error word and the
+ * affected outputs are zero-filled.  smh_model_status waits for `stream`, returns SMH_OK or SMH_E_DEVICE (+ smh_last_error)
+ * and clears the word.  The Python `predict` calls it before it hands results to the caller. */
+int smh_model_status(smh_model *m, void *stream);
 
 /* download the (device-resident, possibly trained) weights in canonical order */
 /* Fusion of the network's first layer into the feature stage (bench fast path; same logits within f32 tolerance):

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmh.so")
 
-SMH_OK, SMH_E_INVALID, SMH_E_HIP, SMH_E_WORKSPACE = 0, -1, -2, -3
+SMH_OK, SMH_E_INVALID, SMH_E_HIP, SMH_E_WORKSPACE, SMH_E_DEVICE = 0, -1, -2, -3, -4
 
 
 class FrontendCfg(C.Structure):
@@ -87,6 +87,7 @@ SIGNATURES = {
     "smh_model_set_weights": (_i, [_vp, _vp, _sz, _vp]),
     "smh_model_out_dim": (_i, [_vp]),
     "smh_model_forward_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
+    "smh_model_status": (_i, [_vp, _vp]),
     "smh_model_w0_ptr": (_vp, [_vp]),
     "smh_features_l0_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _vp]),
     "smh_model_forward_x0_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),

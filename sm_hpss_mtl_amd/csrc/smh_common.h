@@ -31,6 +31,11 @@ inline int launch_status(const char *what) {
     return SMH_OK;
 }
 
+// Timing probes and experiment switches that make a launch's OUTPUTS INVALID (a phase skipped, a store or load left out):
+// read only when SMH_ENABLE_PROBES=1 is set, and every affected launch says so on stderr.  Without that switch the variable is
+// ignored (one notice per variable).  Selectors that keep results valid (kernel A/B choices such as SMH_TCN_SKEW) use getenv.
+const char *probe_env(const char *name);
+
 constexpr int kMaxFftStages = 12;
 constexpr int kLdsBytesPerCU = 160 * 1024;
 

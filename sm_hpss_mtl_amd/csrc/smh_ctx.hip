@@ -18,6 +18,23 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+const char *probe_env(const char *name) {
+    const char *v = getenv(name);
+    if (!v) return nullptr;
+    const char *sw = getenv("SMH_ENABLE_PROBES");
+    if (!sw || atoi(sw) != 1) {
+        static thread_local char noticed[16][48];
+        static thread_local int n_noticed = 0;
+        for (int i = 0; i < n_noticed; ++i)
+            if (!strncmp(noticed[i], name, 47)) return nullptr;
+        if (n_noticed < 16) strncpy(noticed[n_noticed++], name, 47);
+        fprintf(stderr, "libsmh: %s is a probe that invalidates outputs; ignored (set SMH_ENABLE_PROBES=1 to use it)\n", name);
+        return nullptr;
+    }
+    fprintf(stderr, "libsmh: PROBE %s=%s active -- this launch's outputs are NOT results\n", name, v);
+    return v;
+}
+
 }  // namespace smh
 
 extern "C" const char *smh_last_error(void) { return smh::g_err; }

@@ -1158,7 +1158,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
     fp.plan = c->d_feat_plan;
     fp.trace = g_feat_trace;
-    const char *stop_ev = getenv("SMH_FEAT_STOP");  // tuning only
+    const char *stop_ev = smh::probe_env("SMH_FEAT_STOP");  // timing probe: the kernel returns early
     const int stop = stop_ev ? atoi(stop_ev) : 0;
     if (pair) {
         // half the LDS per workgroup: two share a CU.  The 8 waves take the 8-segment plan, one segment each: every segment

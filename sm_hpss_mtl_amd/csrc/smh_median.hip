@@ -208,7 +208,7 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
         if (make_split_roles(K, p.TT, lh, lp, se->threads / 64, &q)) {
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)se->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds));
             dim3 grid(q.ntiles, B), block((q.nwh + q.nwp) * 64);
-            static const bool probe_noload = getenv("SMH_MEDIAN_PROBE_NOLOAD") != nullptr;  // timing experiment, outputs invalid
+            const bool probe_noload = smh::probe_env("SMH_MEDIAN_PROBE_NOLOAD") != nullptr;  // timing experiment, outputs invalid
             hipLaunchKernelGGL(se->fn, grid, block, q.lds, st, S, harm, perc, K, T, q.TT, q.stride, q.nsh, q.nsp, q.nwh,
                                harm_tmajor, probe_noload ? 1.f : -__builtin_inff(), __builtin_inff());
             return smh::launch_status("hpss_median_split_kernel");

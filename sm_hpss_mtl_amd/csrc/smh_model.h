@@ -25,6 +25,8 @@ struct TcnArgs {
     int wlds;     // block weights staged through two LDS slots (0: read from L2 by every wave -- patches too long for the slots)
     unsigned long long *trace;  // tools only (tools/trace_model.py): per-task timestamps of workgroup 0, or nullptr
     int tune;     // experiment switches of the skewed schedule (SMH_TCN_TUNE; tools only)
+    int *status;  // device error word of the model (smh_model_status): bit 0 = a wave of the skewed schedule gave up on a dependency
+    int spin_limit;  // polls before a wave of the skewed schedule gives up (kSkewSpinLimit; lowered only by the debug knob of the test)
     int from_x0;  // X holds the two per-half partials of layer 0, (N, 2, T, 32) (smh_features_l0_f32), instead of patches
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];
@@ -73,6 +75,10 @@ struct smh_model {
     // bf16 operand cache of smh_model_forward_bf16 (smh_tcn_bf16.hip): rebuilt when `version` moves
     void *d_bf16 = nullptr;
     unsigned long long version = 1, bf16_version = 0;
+    // Device error word (smh_model_status).  A kernel that cannot produce results -- today: a wave of the skewed schedule whose
+    // dependency never arrived within its bounded spin -- ORs a bit in and zero-fills its workgroup's outputs; the host reads
+    // and clears it in smh_model_status.  Never a NaN payload: smh_tcn.hip is compiled -fno-honor-nans.
+    int *d_status = nullptr;
 };
 
 namespace smh_tcn {

@@ -408,7 +408,7 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         const size_t lds = sizeof(float2) * (200 + 202 + 200 + (size_t)F * kMP400);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft400_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((T + F - 1) / F, B), block(nthreads);
-        static const int probe = getenv("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
+        const int probe = smh::probe_env("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
         hipLaunchKernelGGL(stft400_kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
                            ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe);
         return smh::launch_status("stft400_kernel");

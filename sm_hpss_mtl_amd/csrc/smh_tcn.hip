@@ -449,6 +449,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         load_block_lds(w0, Wb, lane, q);
         __syncthreads();  // x0, zero rows, flags
         save_acts(xin, 0);  // (training) the input of block 0; every later slot is written by the task that produces it
+        // save_acts copies rows of xa striding over ALL tiles, and block-1 tasks write their outputs back into xa: the flags only
+        // order tasks, not this copy, so every wave's share of it is finished before any task starts (one barrier per launch)
+        if constexpr (TRAIN) __syncthreads();
         if (tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
             a.trace[4 * (2000 + blockIdx.x)] = __builtin_amdgcn_s_memtime();
             a.trace[4 * (2000 + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -533,7 +536,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 const int have = done[lane];
                 if (stands(have, blk, mask)) break;
                 if (__any(lane == 63 && have != 0)) break;
-                if (spins > kSkewSpinLimit) {
+                if (spins > a.spin_limit) {
                     if (lane == 0) done[63] = 1;
                     break;
                 }
@@ -555,7 +558,8 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         auto publish = [&]() {
             if (pend_u >= 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the finished task's rows are in LDS before its flag moves
-                if (lane == 0) done[pend_u] = pend_v;
+                // (a.tune & 256, test_skew_give_up_is_reported only: wave 1 never publishes -- its dependants must give up)
+                if (lane == 0 && !((a.tune & 256) && wave == 1)) done[pend_u] = pend_v;
                 pend_u = -1;
             }
         };
@@ -740,9 +744,10 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     if constexpr (MODE == kSkew) gave_up = ((__attribute__((address_space(3))) volatile int *)(ws))[63] != 0;  // the heads do not touch ws
     dense_and_heads<TRAIN>(a, xin, xout, WhA, hp, out, tio, n0, g_here);
     if (tracing && blockIdx.x < 256 && threadIdx.x == 0) a.trace[4 * 3000 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    if (gave_up) {  // a dependency never arrived: the outputs are not results
+    if (gave_up) {  // a dependency never arrived: the outputs are not results -- say so in the model's error word
         __syncthreads();
-        for (int i = threadIdx.x; i < g_here * a.out_dim; i += blockDim.x) out[(size_t)n0 * a.out_dim + i] = __builtin_nanf("");
+        for (int i = threadIdx.x; i < g_here * a.out_dim; i += blockDim.x) out[(size_t)n0 * a.out_dim + i] = 0.f;
+        if (threadIdx.x == 0 && a.status) atomicOr(a.status, 1);
     }
 }
 
@@ -896,6 +901,7 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     a.tune = 0;
     a.trace = nullptr;
     a.from_x0 = 0;
+    a.status = m->d_status, a.spin_limit = kSkewSpinLimit;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
     for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
@@ -931,9 +937,11 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     size_t lds;
     fill_args(m, N, &a, &lds);
     a.from_x0 = from_x0;
-    if (const char *ev = getenv("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tuning only (tools/tune_model.py)
-    a.skip_heads = getenv("SMH_TCN_NOHEADS") ? 1 : 0;
-    if (const char *ev = getenv("SMH_TCN_TUNE")) a.tune = atoi(ev);
+    // timing probes (outputs invalid; training would read stale activations): only under SMH_ENABLE_PROBES=1, announced on stderr
+    if (const char *ev = smh::probe_env("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tools/tune_model.py
+    a.skip_heads = smh::probe_env("SMH_TCN_NOHEADS") ? 1 : 0;
+    if (const char *ev = smh::probe_env("SMH_TCN_TUNE")) a.tune = atoi(ev);
+    if (a.tune & 256) a.spin_limit = 1 << 10;  // test_skew_give_up_is_reported: a withheld flag must end in the error word quickly
     a.trace = g_trace ? g_trace + (g_trace_launches++ & 1) * kTraceWords : nullptr;  // consecutive launches alternate halves
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
     // waves per workgroup: the block time is (column tiles of the busiest wave) x (time per tile) plus a fixed part, so
@@ -955,7 +963,9 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     // (tools/time_model_sizes.py, W = 68: 17 tiles 149 against 160 us, 13 tiles 130 / 134; 9 tiles 107 / 105.5; 5 tiles -- up to 256
     // patches, one per workgroup -- 97 / 77: fewer tiles than waves, every task waits on the block before; W = 249, 16 tiles = two
     // full rounds of the 8 waves: 162 / 154).  SMH_TCN_SKEW=0 / 2: never / whenever it can run (tests, tuning).
-    const bool skew_ok = a.wlds && units <= 32 && units >= 1;
+    // (the schedule decodes task n into (block, tile) by multiplication, exact for n < 2048: smh_model_create accepts up to
+    // nb_stacks x 16 dilations, the reference tunes nb_stacks up to 10 -- beyond the bound the barrier schedule runs)
+    const bool skew_ok = a.wlds && units <= 32 && units >= 1 && a.n_blocks * units < 2048;
     bool skew = skew_ok && units >= 12 && 8 * ((units + 7) / 8) - units >= 3;
     if (const char *ev = getenv("SMH_TCN_SKEW")) skew = atoi(ev) == 2 ? skew_ok : (skew && atoi(ev) != 0);
     if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
@@ -1046,6 +1056,8 @@ extern "C" int smh_model_create(const smh_model_cfg *cfg, smh_model **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_map, npk * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(m->d_map, map.data(), npk * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(m->d_flat, 0, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_status, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->d_status, 0, sizeof(int));
     if (e != hipSuccess) {
         smh_model_destroy(m);
         return smh::set_error(SMH_E_HIP, "smh_model_create: device allocation failed: %s", hipGetErrorString(e));
@@ -1063,7 +1075,20 @@ extern "C" void smh_model_destroy(smh_model *m) {
     (void)hipFree(m->d_W0);  // base of the four operand buffers
     (void)hipFree(m->d_map);
     (void)hipFree(m->d_bf16);
+    (void)hipFree(m->d_status);
     delete m;
+}
+
+extern "C" int smh_model_status(smh_model *m, void *stream) {
+    SMH_REQUIRE(m, "smh_model_status: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int word = 0;
+    SMH_CHECK_HIP(hipMemcpyAsync(&word, m->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    SMH_CHECK_HIP(hipStreamSynchronize(st));
+    if (word == 0) return SMH_OK;
+    SMH_CHECK_HIP(hipMemsetAsync(m->d_status, 0, sizeof(int), st));
+    return smh::set_error(SMH_E_DEVICE, "B3_MTL forward: device error word 0x%x (bit 0: a wave of the skewed block schedule gave up "
+                          "waiting for a dependency; the affected outputs were zero-filled and are not results)", word);
 }
 
 extern "C" size_t smh_model_num_params(const smh_model *m) { return m ? m->n_params : 0; }

@@ -25,10 +25,31 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def visible_gpus() -> int:
-    """Number of GPUs without initialising HIP in this process (torch counts devices through the SMI library)."""
-    import torch
-    return int(torch.cuda.device_count())
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def visible_gpus(kfd_nodes: str = KFD_NODES) -> int:
+    """Number of GPUs this process would see, WITHOUT loading torch or any HIP / HSA library: the parent of the ranks must never
+    initialise the GPU, and `torch.cuda.device_count()` falls back to hipGetDeviceCount when amdsmi is not importable.
+    Counts the KFD topology nodes that have SIMDs (CPU nodes have none), then applies the ROCR / HIP / CUDA visibility lists the
+    runtime would apply.  No KFD (a CPU-only machine) = 0."""
+    n = 0
+    try:
+        for node in sorted(os.listdir(kfd_nodes)):
+            try:
+                with open(os.path.join(kfd_nodes, node, "properties")) as f:
+                    props = dict(line.split(None, 1) for line in f if " " in line)
+                if int(props.get("simd_count", "0").strip()) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def spawn_ranks_if_needed(n_gpus: int, script: str, argv, backend=None):
@@ -98,7 +119,7 @@ def init_ranks(n_gpus: int, backend=None) -> Ranks:
     backend = backend or os.environ.get("SMH_DIST_BACKEND", "nccl")
     import torch
     if backend == "nccl":
-        have = visible_gpus()
+        have = int(torch.cuda.device_count())  # a rank is allowed to touch the GPU (it is about to)
         if local_rank >= have:
             raise SystemExit("error: rank %d has no GPU (LOCAL_RANK=%d, %d visible)" % (rank, local_rank, have))
         torch.cuda.set_device(local_rank)

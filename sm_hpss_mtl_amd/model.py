@@ -220,17 +220,19 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         N = x.shape[0]
         if out is None:
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x.device)
-        if dtype in ("bf16", "bf16_plain"):
-            # "bf16": hi + lo split operands, three bf16 products per f32 product (within 2e-2 of f32: BASELINE config 5);
-            # "bf16_plain": operands rounded to one bf16 (faster, 3.5-5e-2 from f32: measurement only)
+        if dtype == "bf16":
+            # "bf16" = SPLIT bf16 operands: every f32 operand travels as hi + lo (two bf16 values) and every product is three
+            # bf16 MFMA (hi*hi + hi*lo + lo*hi) accumulated in f32 -- f32-grade arithmetic on the bf16 matrix pipe (7e-5 from the
+            # f32 kernel), not an 8-bit-mantissa network.  Operands rounded to ONE bf16 land 3.5-5e-2 from f32, outside SURVEY
+            # 8(d')'s 2e-2, and are not offered here (C ABI: smh_model_forward_bf16_ex(split = 0), measurement only).
             if trunk is not None:
                 raise ValueError("the trunk tap is only available on the f32 path")
             _lib.check(self.lib.smh_model_forward_bf16_ex(
-                self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()), 1 if dtype == "bf16" else 0,
+                self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()), 1,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_bf16")
             return out
         if dtype != "f32":
-            raise ValueError("dtype must be 'f32', 'bf16' or 'bf16_plain'")
+            raise ValueError("dtype must be 'f32' or 'bf16' (split bf16 operands), got %r" % (dtype,))
         _lib.check(self.lib.smh_model_forward_f32(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),
@@ -239,7 +241,7 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
 
     def forward_from_x0(self, x0p, out=None, trunk=None, dtype="f32"):
         """Forward that starts from the per-half layer-0 partials (N, 2, W, 32) written by `Frontend.features_l0`.
-        dtype as for `forward_device`; with "bf16" / "bf16_plain" layer 0 stays exact f32 (it was computed by the feature kernel)."""
+        dtype as for `forward_device`; with "bf16" layer 0 stays exact f32 (it was computed by the feature kernel)."""
         if not (isinstance(x0p, torch.Tensor) and x0p.is_cuda and x0p.dtype == torch.float32):
             raise TypeError("forward_from_x0 expects a float32 CUDA tensor")
         x0p = x0p.contiguous()
@@ -251,15 +253,15 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         N = x0p.shape[0]
         if out is None:
             out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x0p.device)
-        if dtype in ("bf16", "bf16_plain"):
+        if dtype == "bf16":
             if trunk is not None:
                 raise ValueError("the trunk tap is only available on the f32 path")
             _lib.check(self.lib.smh_model_forward_x0_bf16(
-                self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()), 1 if dtype == "bf16" else 0,
+                self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()), 1,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_bf16")
             return out
         if dtype != "f32":
-            raise ValueError("dtype must be 'f32', 'bf16' or 'bf16_plain'")
+            raise ValueError("dtype must be 'f32' or 'bf16' (split bf16 operands), got %r" % (dtype,))
         _lib.check(self.lib.smh_model_forward_x0_f32(
             self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),
@@ -282,4 +284,11 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         elif x.dtype != torch.float32:
             x = x.float()
         out = self.forward_device(x.cuda(), dtype=dtype)
+        self.check_status()  # the forward is stream-ordered: a device-side give-up must become an exception, not a result
         return [o.cpu().numpy() for o in self.split_outputs(out)]
+
+    def check_status(self):
+        """Wait for the current stream and raise RuntimeError if a forward kernel recorded in the model's device error word
+        that its outputs are not results (include/smh.h: smh_model_status).  `forward_device` / `forward_from_x0` only enqueue
+        work; callers that keep results on the device call this before trusting them (`predict` and bench.py do)."""
+        _lib.check(self.lib.smh_model_status(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_status")

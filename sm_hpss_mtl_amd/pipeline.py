@@ -27,7 +27,8 @@ def _p(t):
 class HotPath:
     def __init__(self, fe, model, batch, n_samples, patch=68, shift=None, fuse_l0=True, two_kernel_features=False,
                  model_dtype="f32", keep_patches=False, keep_trunk=False, device=None):
-        """fe: Frontend, model: B3MTL.  fuse_l0: the network's first 1x1 convolution runs inside the feature kernel
+        """fe: Frontend, model: B3MTL, or None for the front end alone (BASELINE config 2, "HPSS-only": three launches, the step
+        ends with the featuregram; no patches, no logits).  fuse_l0: the network's first 1x1 convolution runs inside the feature kernel
         (smh_features_l0_f32 + smh_model_forward_x0_f32) instead of patches -> smh_model_forward_f32.
         keep_patches / keep_trunk: also write the standardised time-major patches / the TCN output (N, W, 32) -- parity taps
         that `model.predict` does not return; never set by bench.py."""
@@ -37,14 +38,14 @@ class HotPath:
         self.model_dtype = model_dtype
         if model_dtype not in ("f32", "bf16"):
             raise ValueError("model_dtype must be 'f32' or 'bf16'")
-        self.fuse_l0 = bool(fuse_l0)  # both network dtypes start from the layer-0 partials
+        self.fuse_l0 = bool(fuse_l0) and model is not None  # both network dtypes start from the layer-0 partials
         self.T = fe.num_frames(self.n_samples)
         if self.T < 1:
             raise ValueError("clip of %d samples is shorter than n_fft=%d" % (n_samples, fe.cfg.n_fft))
-        if model.n_feat != 2 * fe.rows or model.patch_size != self.W:
+        if model is not None and (model.n_feat != 2 * fe.rows or model.patch_size != self.W):
             raise ValueError("model expects (W=%d, n_feat=%d), the front end produces (W=%d, n_feat=%d)"
                              % (model.patch_size, model.n_feat, self.W, 2 * fe.rows))
-        self.nP = fe.num_patches(self.T, self.W, self.shift)
+        self.nP = fe.num_patches(self.T, self.W, self.shift) if model is not None else 0
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         B, K, T, F = self.B, fe.K, self.T, 2 * fe.rows
         f32 = dict(dtype=torch.float32, device=dev)
@@ -53,11 +54,11 @@ class HotPath:
         self.harm = torch.empty((B, self.lib.smh_harm_buffer_floats(K, T)), **f32)  # room for every harm layout
         self.fv = torch.empty((B, F, T), **f32)
         self.maxkeys = torch.empty(2 * max(B, 1), dtype=torch.int32, device=dev)
-        need_patches = keep_patches or not self.fuse_l0
+        need_patches = (keep_patches or not self.fuse_l0) and model is not None
         self.patches = torch.empty((B * self.nP, self.W, F), **f32) if need_patches else None
         self.x0p = torch.empty((B * self.nP, 2, self.W, 32), **f32) if self.fuse_l0 else None
-        self.logits = torch.empty((B * self.nP, model.out_dim), **f32)
-        self.trunk = torch.empty((B * self.nP, self.W, 32), **f32) if (keep_trunk and model_dtype == "f32") else None
+        self.logits = torch.empty((B * self.nP, model.out_dim), **f32) if model is not None else None
+        self.trunk = torch.empty((B * self.nP, self.W, 32), **f32) if (keep_trunk and model_dtype == "f32" and model is not None) else None
         # harmonic median layout: 16-frame blocks when the single feature kernel takes the clip, else time-major
         blocked = self.lib.smh_features_blocked_ok(self._h, T, 1 if self.fuse_l0 else 0) and not two_kernel_features
         self.want_layout = 2 if blocked else 1
@@ -70,7 +71,8 @@ class HotPath:
             raise ValueError("audio must be a float32 device tensor of shape (%d, %d)" % (self.B, self.n_samples))
         lib, h, fe, m = self.lib, self._h, self.fe, self.model
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        m._sync_weights()
+        if m is not None:
+            m._sync_weights()
         if record is not None:
             record[0].record()
         _lib.check(lib.smh_stft_mag_f32(h, _p(audio), self.B, self.n_samples, _p(self.S), st), "smh_stft_mag_f32")
@@ -89,12 +91,16 @@ class HotPath:
                                                      _p(self.maxkeys), st), "smh_features_l0_f32")
         else:
             got = _lib.check(lib.smh_features_ex_f32(h, _p(self.S), _p(self.harm), _p(self.perc), lay, self.B, self.T,
-                                                     self.W, self.shift, _p(self.fv), _p(self.patches),
-                                                     _p(self.maxkeys), st), "smh_features_ex_f32")
+                                                     self.W if m is not None else 0, self.shift if m is not None else 0,
+                                                     _p(self.fv), _p(self.patches), _p(self.maxkeys), st), "smh_features_ex_f32")
         if got != self.nP:
             raise RuntimeError("feature stage produced %d patches per clip, expected %d" % (got, self.nP))
         if record is not None:
             record[3].record()
+        if m is None:
+            if record is not None:
+                record[4].record()
+            return self.fv
         if self.fuse_l0:
             m.forward_from_x0(self.x0p, out=self.logits, trunk=self.trunk, dtype=self.model_dtype)
         else:

@@ -31,6 +31,16 @@ def synth_clips(batch: int, seed: int = 0, n_samples: int = 16000, fs: int = 160
     return out
 
 
+def bench_clips(batch: int, rank: int = 0, n_samples: int = 16000) -> np.ndarray:
+    """The batch bench.py times on rank `rank`: `batch` DISTINCT clips -- rows 0..63 = synth_clips(64, seed=1000 + rank) (the
+    clips tests/golden/bench_golden.npz holds oracle logits for), rows 64.. = synth_clips(batch - 64, seed=5000 + rank) (the
+    golden file also holds rows 64 and 65).  Nothing is tiled: every step reads batch x 64 000 bytes of different audio."""
+    head = synth_clips(min(batch, 64), seed=1000 + rank, n_samples=n_samples)
+    if batch <= 64:
+        return head
+    return np.concatenate([head, synth_clips(batch - 64, seed=5000 + rank, n_samples=n_samples)], axis=0)
+
+
 # (n_samples, [(start_s, end_s) of near-silent stretches]) -- the cases of tests/golden/silence_golden.npz
 SILENCE_CASES = (
     (32000, ((0.2, 0.5), (1.0, 1.3))),              # two runs -> removal

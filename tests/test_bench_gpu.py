@@ -19,12 +19,12 @@ def _json_line(cmd):
 
 
 def test_bench_contract():
-    d = _json_line(["bench.py", "--steps", "4", "--warmup", "1", "--batch", "128", "--cpu-budget", "2"])
+    d = _json_line(["bench.py", "--steps", "4", "--warmup", "1", "--batch", "128", "--cpu-budget", "2", "--steady-steps", "3"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "clips/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"].startswith("synthetic")
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] == pytest.approx(128 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-3)
     rf = d["roofline"]
@@ -37,8 +37,30 @@ def test_bench_contract():
     assert set(d["kernels"]) >= {"stft", "median", "features", "model"}
     # the timed configuration was checked against the oracle's committed logits inside bench.py
     pr = d["parity"]
-    assert pr["checked"] is True and pr["argmax_3C_identical"] is True and pr["max_abs_logit_diff_vs_oracle_golden"] <= pr["tol"]
+    assert pr["checked"] is True and pr["argmax_identical"] is True and pr["max_abs_logit_diff_vs_oracle_golden"] <= pr["tol"]
+    assert pr["clips"] == 6   # rows 0..3 and the two golden rows behind the first 64: the batch is distinct clips, not a tiling
     assert d["config"]["harm_layout"] == 2 and d["ranks_reporting"] == 1
+    # the caller's W / K are what ran: no hidden pre-roll; the steady-state figure is a separate field
+    assert "preroll_steps" not in d and d["steady_state"]["steps"] == 3 and d["steady_state"]["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("workload,unit,dominant", [("config2", "clips/s", "hbm"), ("config3", "patches/s", "mfma"),
+                                                    ("config5", "clips/s", None)])
+def test_bench_other_baseline_configs_print_a_full_line(workload, unit, dominant):
+    """BASELINE configs 2, 3 and 5 on one GPU: each a full line with `roofline`, checked against the committed oracle logits
+    where the workload ends in logits."""
+    d = _json_line(["bench.py", "--workload", workload, "--steps", "4", "--warmup", "1", "--steady-steps", "0"])
+    assert d["unit"] == unit and d["config"]["name"] == workload and d["value"] > 0 and "steady_state" not in d
+    rf = d["roofline"]
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and (dominant is None or rf["bound"] == dominant)
+    if workload == "config2":
+        assert set(d["kernels"]) == {"stft", "median", "features"} and d["parity"]["checked"] is False
+    else:
+        assert d["parity"]["checked"] is True and d["parity"]["max_abs_logit_diff_vs_oracle_golden"] <= d["parity"]["tol"]
+    if workload == "config3":
+        assert d["config"]["patches_per_gpu"] == 256 and set(d["kernels"]) == {"model"}
+    if workload == "config5":
+        assert "split bf16" in d["dtype"] and d["config"]["l_harm"] == 21
 
 
 def test_bench_train_contract():

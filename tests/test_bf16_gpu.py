@@ -1,8 +1,11 @@
-"""Mixed-precision B3_MTL forward (bf16 matrix-core operands, f32 accumulation / residual stream / normalisation):
-BASELINE config 5.  It is NOT the parity path; this file states how far it is from the f32 path and the oracle.
-  dtype="bf16"        hi + lo split operands, three bf16 products per f32 product: inside SURVEY 8(d')'s bf16 tolerance
-                      (abs 2e-2, argmax agreement >= 99.5 %); measured ~1e-3.
-  dtype="bf16_plain"  one bf16 per operand: 3.5-5e-2 through the 24 normalised blocks -- outside; kept for measurement."""
+"""B3_MTL forward on the bf16 matrix pipe (BASELINE config 5 reads "mixed bf16 CNN + fp32 HPSS").  Stated plainly:
+  dtype="bf16" is SPLIT-operand arithmetic -- every f32 operand travels as hi + lo (two bf16 values, 16 mantissa bits), every
+  product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with f32 accumulation, residual stream and normalisation.  That is
+  f32-grade arithmetic carried by bf16 instructions (three of them per f32 product), NOT an 8-bit-mantissa network: it is held
+  here to 2e-4 of the f32 kernel (measured 7-8e-5), two orders inside SURVEY 8(d')'s 2e-2.
+  A network with ONE bf16 per operand (C ABI smh_model_forward_bf16_ex(split = 0); not offered by the Python surface) lands
+  3.5-5e-2 from f32 after 24 blocks of 'divide by the channel maximum' -- outside the 2e-2 tolerance.  The last test states that
+  distance so the claim stays measured; it is the reason config 5 is served by the split form."""
 import numpy as np
 import pytest
 import torch
@@ -13,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 # measured on seeded random weights with perturbed BatchNorm statistics (the hardest case for rounding: 24 blocks of
 # 'divide by the channel maximum'): max |output difference| 2-4e-2, argmax of the 3C head identical on > 99.5 %
-TOL_ABS = 6e-2          # bf16_plain
-TOL_SPLIT = 2e-2        # bf16 (split operands): the SURVEY 8(d') tolerance
+TOL_SPLIT = 2e-4        # "bf16" = split operands (measured 7-8e-5; SURVEY 8(d') would allow 2e-2)
+SINGLE_BF16_BAND = (2e-2, 8e-2)   # one bf16 per operand: measured 3.5-5e-2, i.e. OUTSIDE SURVEY 8(d')'s 2e-2
 MIN_AGREE = 0.995
 
 
@@ -32,7 +35,7 @@ def test_bf16_forward_close_to_f32(ncls, W, N, seed):
     x = torch.randn((N, W, 240), device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
     ref = m.forward_device(x)                      # f32 path (itself within 1e-4 of the oracle)
     small = np.concatenate(b3_mtl.forward(x[:8].cpu().numpy(), w, ncls), axis=1)   # the numpy oracle
-    for dtype, tol in (("bf16", TOL_SPLIT), ("bf16_plain", TOL_ABS)):
+    for dtype, tol in (("bf16", TOL_SPLIT),):
         got = m.forward_device(x, dtype=dtype)
         torch.cuda.synchronize()
         assert got.shape == ref.shape and torch.isfinite(got).all()
@@ -53,8 +56,9 @@ def test_bf16_operands_follow_weight_updates():
     ref = m.forward_device(x)
     torch.cuda.synchronize()
     assert not torch.equal(a, b) and float((b - ref).abs().max()) <= TOL_SPLIT
-    with pytest.raises(ValueError):
-        m.forward_device(x, dtype="fp8")
+    for bad in ("fp8", "bf16_plain"):   # the single-bf16 network is not part of the Python surface
+        with pytest.raises(ValueError):
+            m.forward_device(x, dtype=bad)
 
 
 @pytest.mark.parametrize("ncls,seed", [(3, 5), (5, 6)])
@@ -81,3 +85,20 @@ def test_bf16_from_layer0_partials_end_to_end(ncls, seed):
         assert err <= tol and agree >= MIN_AGREE
     small = np.concatenate(b3_mtl.forward(ref.patches[:8].cpu().numpy(), w, ncls), axis=1)
     assert np.max(np.abs(got[:8].cpu().numpy() - small)) <= TOL_SPLIT
+
+
+def test_single_bf16_operands_miss_the_tolerance():
+    """Why config 5 is not served by a plain bf16 network: operands rounded to one bf16 (the C ABI's split = 0, reachable for
+    measurement only) end 3.5-5e-2 from the f32 kernel on the hardest seeded weights -- outside SURVEY 8(d')'s 2e-2."""
+    import ctypes as C
+    from sm_hpss_mtl_amd import _lib
+    m, _ = _model(3, 68, 7)
+    x = torch.randn((1024, 68, 240), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    ref = m.forward_device(x)
+    got = torch.empty_like(ref)
+    _lib.check(m.lib.smh_model_forward_bf16_ex(m._h, C.c_void_p(x.data_ptr()), 1024, C.c_void_p(got.data_ptr()), 0,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_bf16_ex")
+    torch.cuda.synchronize()
+    err = float((got - ref).abs().max())
+    print("single bf16 operands vs f32: max abs %.3e" % err)
+    assert SINGLE_BF16_BAND[0] < err < SINGLE_BF16_BAND[1]

@@ -30,8 +30,8 @@ def test_self_launch_two_ranks_gloo(script):
 
 
 def test_more_gpus_than_visible_is_an_error():
-    import torch
-    have = torch.cuda.device_count()
+    from sm_hpss_mtl_amd.launch import visible_gpus
+    have = visible_gpus()
     r = _run(["bench.py", "--gpus", str(have + 2), "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "refusing" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -55,3 +55,33 @@ def test_parent_does_not_load_the_hip_library():
             "import torch; assert not torch.cuda.is_initialized()")
     r = _run(["-c", code])
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_gpu_count_of_the_parent_reads_the_kfd_topology_only(tmp_path, monkeypatch):
+    """`visible_gpus` (the nccl parent path) counts KFD nodes with SIMDs and applies the visibility lists -- no torch, no HIP."""
+    from sm_hpss_mtl_amd import launch
+    for i, simd in enumerate((0, 256, 256, 256)):   # node 0: the CPU
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert launch.visible_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert launch.visible_gpus(str(tmp_path)) == 2
+    assert launch.visible_gpus(str(tmp_path / "missing")) == 0
+
+
+def test_nccl_parent_maps_no_gpu_runtime():
+    """The nccl parent path (no SMH_DIST_BACKEND override): asking for more GPUs than the topology shows must be refused by a
+    parent that has mapped neither libamdhip64 / libhsa-runtime64 nor libsmh -- checked in /proc/self/maps of that process."""
+    code = ("import sys, os; sys.argv=['bench.py','--gpus','64','--steps','1','--warmup','0'];"
+            "os.environ.pop('SMH_DIST_BACKEND', None);"
+            "import runpy\n"
+            "try:\n  runpy.run_path('bench.py', run_name='__main__')\n"
+            "except SystemExit as e:\n  assert e.code == 2, e.code\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'libamdhip64' not in maps and 'libhsa-runtime64' not in maps and 'libsmh' not in maps, 'parent mapped a GPU runtime'")
+    r = _run(["-c", code])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "refusing" in r.stderr

@@ -61,7 +61,7 @@ def main():
     shift = args.shift or (24 if W == 249 else W)
     fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
     model = B3MTL(n_feat=240, patch_size=W, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
-    audio = torch.from_numpy(np.tile(synth_clips(64, seed=2000 + rank), ((B + 63) // 64, 1))[:B]).cuda()
+    audio = torch.from_numpy(synth_clips(B, seed=2000 + rank)).cuda()  # B distinct clips per rank
     smr = np.array([(-5, 0, 5, 10, 15, 20)[i % 6] for i in range(bs)], np.float64)
     lab = make_labels_3class(bs, smr) if args.classes == 3 else make_labels_5class(bs, smr, smr[::-1].copy())
     nP = fe.num_patches(fe.num_frames(audio.shape[1]), W, shift)  # short clips are tiled along time first (preprocessing.py:139-142)
