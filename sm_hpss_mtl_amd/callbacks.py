@@ -20,11 +20,18 @@ import numpy as np
 
 
 class Callback:
+    """`is_writer`: data-parallel training runs the same callbacks on every rank with identical logs (fit all-reduces them), so
+    every rank takes the same decisions; only the writer (rank 0) touches the file system."""
+
     def __init__(self):
         self.model = None
+        self.is_writer = True
 
     def set_model(self, model):
         self.model = model
+
+    def set_writer(self, is_writer):
+        self.is_writer = bool(is_writer)
 
     def on_train_begin(self, logs=None):
         pass
@@ -94,6 +101,8 @@ class ModelCheckpoint(Callback):
         self.monitor_op, self.best = _monitor_op(mode, monitor)
 
     def _save(self, path):
+        if not self.is_writer:  # data parallel: replicas are identical, rank 0 writes the one file
+            return
         self.model.save_weights(path)
         if not self.save_weights_only:  # whole-model save: the architecture goes next to the weights
             with open(os.path.splitext(path)[0] + ".json", "w") as f:
@@ -123,10 +132,14 @@ class CSVLogger(Callback):
         self.keys, self._file, self._writer = None, None, None
 
     def on_train_begin(self, logs=None):
+        if not self.is_writer:
+            return
         self._append_header = not (self.append and os.path.exists(self.filename) and os.path.getsize(self.filename) > 0)
         self._file = open(self.filename, "a" if self.append else "w", newline="")
 
     def on_epoch_end(self, epoch, logs=None):
+        if not self.is_writer:
+            return
         logs = logs or {}
         if self.keys is None:
             self.keys = sorted(logs.keys())

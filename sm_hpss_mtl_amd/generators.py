@@ -12,6 +12,15 @@ the HIP front end together as ONE ragged device batch (`Frontend.run_ragged`); p
 tensors in the network's (N, W, 2F) layout.  Per-file results do not depend on what else is in the batch, so the yielded
 batches are the ones the sequential loop would yield.
 
+Data parallel (SURVEY 8e "class-balanced batch composition must be preserved globally, not per rank"): `generator(...,
+rank=, world=)` -- defaulting to the initialised torch.distributed process group -- builds the SAME globally class-balanced
+batch of 3 * batchSize rows on every rank (same file lists, same numpy random state: the caller seeds numpy identically on all
+ranks, exactly as a single process would be seeded; nothing is seeded here) and hands rank r the rows
+`sharding.shard_indices(3 * batchSize, r, world)` of it with their labels: the union over the ranks IS the single-process
+batch, row for row.  Ranks whose numpy state has drifted apart would silently train on different "global" batches, so the
+state is compared across the ranks on the first batch and every `check_every` batches (one tiny all-reduce) and a mismatch
+raises.
+
 `featuregram_fn` / `patches_fn` are injection points for tests (and for a CPU oracle): per-file callables with the
 signatures of `preproc.get_featuregram` / `preproc.get_feature_patches`.  When they are given, files are processed one
 by one through them, exactly like the reference's loop.
@@ -123,8 +132,49 @@ def _n_patches_of_file(PARAMS, path, n_fft, W, shift, lengths_cache):
     return lib.smh_num_patches(lib.smh_tiled_frames(T, int(W)), int(W), int(shift))
 
 
-def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches_fn=None):
+def _rank_world(rank, world):
+    """(rank, world, dist): explicit arguments, else the initialised process group, else a single process."""
+    dist = None
+    try:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized():
+            dist = td
+    except ImportError:  # pragma: no cover
+        pass
+    if world is None:
+        world = dist.get_world_size() if dist is not None else 1
+    if rank is None:
+        rank = dist.get_rank() if dist is not None else 0
+    if not (0 <= int(rank) < int(world)):
+        raise ValueError("rank %r outside world %r" % (rank, world))
+    if dist is not None and dist.get_world_size() != int(world):
+        dist = None  # an explicit (rank, world) that is not the process group's: no cross-rank check possible
+    return int(rank), int(world), dist
+
+
+def _numpy_state_word():
+    """A 52-bit digest of numpy's global random state (what decides every future shuffle / choice of the generator)."""
+    import zlib
+    st = np.random.get_state()
+    return float((zlib.crc32(st[1].tobytes()) ^ (int(st[2]) * 2654435761)) & ((1 << 52) - 1))
+
+
+def _check_same_state(dist, batch_count):
+    import torch
+    w = _numpy_state_word()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([w, -w], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo, hi = -float(t[1]), float(t[0])
+    if lo != hi:
+        raise RuntimeError("data-parallel generator: numpy's random state differs between the ranks at batch %d -- every rank must "
+                           "seed numpy identically (the ranks build the same global batch and take their rows of it)" % batch_count)
+
+
+def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches_fn=None, rank=None, world=None, check_every=50):
     """Infinite class-balanced batch generator: yields (batchData, labels).
+    rank / world (default: the torch.distributed process group, else one process): this rank's rows
+    shard_indices(n_rows, rank, world) of every GLOBAL batch -- batchSize stays the global per-class batch size.
 
     batchData: [batchSize music | batchSize speech | batchSize speech+music] patches, (3*batchSize, W, 2F) for the TCN
     models ((.., 2F, W, 1) for the Conv2D ones when the per-file callables are injected); labels: {'R', 'S', 'M', '3C'} for
@@ -147,6 +197,8 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
     if PARAMS.get('frame_level_scaling') or PARAMS.get('skewness_vector'):
         raise ValueError("frame_level_scaling / skewness_vector are off in every reference configuration of this path "
                          "(Proposed_Work_Results.py:802-804) and are not wired into the generator")
+    from .sharding import shard_indices
+    rank, world, dist = _rank_world(rank, world)
     per_file = featuregram_fn is not None or patches_fn is not None
     if per_file:
         from .lib import preprocessing as pp
@@ -219,21 +271,35 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
             fill('speech_music', next_mix)
             data_mix, smr = buf['speech_music'].take(batchSize)
             parts.append(data_mix)
-        if isinstance(parts[0], np.ndarray):
+        host_batch = isinstance(parts[0], np.ndarray)
+        mine = shard_indices(sum(int(p.shape[0]) for p in parts), rank, world) if world > 1 else None
+        if host_batch:
             batchData = np.concatenate(parts, axis=0)
             if 'Lemaire_et_al' in PARAMS['Model']:
                 batchData = np.transpose(batchData, axes=(0, 2, 1))  # per-file callables return (nP, F, W)
+            # host batches draw their noise from numpy's global state: augment the GLOBAL batch, then take this rank's rows,
+            # so that every rank consumes the same random numbers and the states stay in step
+            if PARAMS['data_augmentation_with_noise']:
+                batchData = batching.noise_augmentation(batchData, rng)
+            if mine is not None:
+                batchData = batchData[mine]
         else:
             import torch
             batchData = torch.cat(parts, dim=0)  # device patches are already (N, W, F)
-        if PARAMS['data_augmentation_with_noise']:
-            batchData = batching.noise_augmentation(batchData, rng)
+            if mine is not None:
+                batchData = batchData[torch.as_tensor(mine, device=batchData.device)]
+            if PARAMS['data_augmentation_with_noise']:  # the scale from numpy (same on all ranks), the noise from torch's generator
+                batchData = batching.noise_augmentation(batchData, rng)
         if three:
             lab = batching.make_labels_3class(batchSize, np.asarray(smr, dtype=np.float64))
         else:  # two classes: only music / speech rows
             lab = batching.make_labels_3class(batchSize, np.zeros(batchSize))
             lab = {k: v[:2 * batchSize] for k, v in lab.items()}
             lab['3C'] = to_categorical([0] * batchSize + [1] * batchSize, 2)
+        if mine is not None:
+            lab = {k: v[mine] for k, v in lab.items()}
+            if dist is not None and check_every and batch_count % int(check_every) == 0:
+                _check_same_state(dist, batch_count)
         batch_count += 1
         if 'MTL' in PARAMS['Model']:
             yield batchData, lab

@@ -10,6 +10,18 @@ momentum=0.9, clipnorm=1).  All arithmetic runs in libsmh (HIP); torch supplies 
 dropout masks and -- for data parallel training -- ONE all-reduce of the bucket [flat gradient | BatchNorm batch
 statistics] over RCCL.  Nothing in a step reads the device back: the losses of an epoch are summed on the device and
 copied to the host once per epoch (`train_on_batch` returns host floats, as Keras does, unless sync=False).
+
+Data parallel (torch.distributed initialised, world > 1).  Replicas start identical, every step applies the same
+averaged gradient, so they stay identical -- and everything that DECIDES must see the same numbers on every rank, or one
+rank leaves the loop while the others wait in the next all-reduce:
+  * per step: one SUM all-reduce of the bucket (apply_gradients);
+  * per epoch: the epoch's training losses and the validation losses are all-reduced (row-weighted mean over the ranks'
+    shards = the loss of the global batch) and the resulting logs broadcast from rank 0, BEFORE the callbacks see them:
+    EarlyStopping, ModelCheckpoint and restore-best take the same decision everywhere; a `stop_training` set on any rank
+    (a user callback) stops all of them (MAX all-reduce);
+  * rank 0 alone writes the checkpoint and the CSV log (`Callback.is_writer`);
+  * the generator hands rank r the rows `shard_indices(3 * batchSize, r, world)` of each globally class-balanced batch
+    (sm_hpss_mtl_amd.generators.generator), so class balance is a property of the global batch, not of a rank's draw.
 """
 from __future__ import annotations
 
@@ -36,6 +48,26 @@ _LOSS_OF = {"S": "binary_crossentropy", "M": "binary_crossentropy", "N": "binary
 
 def _cur_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def process_group():
+    """torch.distributed when a process group with more than one rank is initialised, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _host_collective(values, op, dist, src=None):
+    """A small host-side float64 vector through the process group (RCCL needs device tensors, gloo takes host ones):
+    op = 'sum' | 'max' all-reduce, or 'bcast' from rank `src`.  Returns a numpy array identical on every rank."""
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(np.asarray(values, dtype=np.float64), dtype=torch.float64, device=dev)
+    if op == "bcast":
+        dist.broadcast(t, src=src or 0)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+    return t.cpu().numpy()
 
 
 def train_head_bit(h):
@@ -315,17 +347,28 @@ class TrainingMixin:
         bad = [k for k in kwargs if k not in _FIT_IGNORED + ("callbacks", "return_dict")]
         if bad or kwargs.get("return_dict"):
             raise TypeError("evaluate: unsupported arguments %s" % sorted(bad or ["return_dict"]))
+        # Row-weighted sums: under data parallel every rank evaluates its own shard of every batch and the all-reduce below
+        # turns the shard means into the mean over the global batch -- the number a single device would report, and the SAME
+        # number on every rank (EarlyStopping / ModelCheckpoint decide on it).  Single process: a plain mean over the batches.
+        dist = process_group()
         if y is not None:
-            return self._losses_inference(x, y)
-        if steps is None:
-            raise ValueError("evaluate(generator) needs steps=")
-        tot, cnt = None, 0
-        for _ in range(int(steps)):
-            bx, by = next(x)
-            v = np.array(self._losses_inference(bx, by))
-            tot = v if tot is None else tot + v
-            cnt += 1
-        return list(tot / max(cnt, 1))
+            v = np.array(self._losses_inference(x, y), np.float64)
+            rows = float(len(x))
+            tot, cnt = v * rows, rows
+        else:
+            if steps is None:
+                raise ValueError("evaluate(generator) needs steps=")
+            tot, cnt = None, 0.0
+            for _ in range(int(steps)):
+                bx, by = next(x)
+                rows = float(len(bx)) if dist is not None else 1.0  # Keras averages the batch values (equal batch sizes)
+                v = np.array(self._losses_inference(bx, by), np.float64) * rows
+                tot = v if tot is None else tot + v
+                cnt += rows
+        if dist is not None:
+            red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
+            tot, cnt = red[:-1], red[-1]
+        return list(tot / max(cnt, 1.0))
 
     # ---- fit ------------------------------------------------------------------------------------------
     def _train_step_raw(self, bx, by):
@@ -354,8 +397,11 @@ class TrainingMixin:
         elif steps_per_epoch is None:
             raise ValueError("fit(generator) needs steps_per_epoch=")
         self.stop_training = False
+        dist = process_group()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
         for cb in cbs:
             cb.set_model(self)
+            cb.set_writer(rank == 0)
             cb.on_train_begin()
         for ep in range(int(initial_epoch), int(epochs)):
             t0 = time.time()
@@ -368,7 +414,11 @@ class TrainingMixin:
                     bx, by = next(x)
                 raw = self._train_step_raw(bx, by)
                 acc = raw.clone() if acc is None else acc.add_(raw)
-            mean = self.losses_to_list(acc / float(max(int(steps_per_epoch), 1)))
+            mean_raw = acc / float(max(int(steps_per_epoch), 1))
+            if dist is not None:  # the training loss of the GLOBAL batch: mean over the ranks' (equal-sized) shards
+                dist.all_reduce(mean_raw, op=dist.ReduceOp.SUM)
+                mean_raw = mean_raw / float(world)
+            mean = self.losses_to_list(mean_raw)
             logs = {n: float(v) for n, v in zip(names, mean)}
             if validation_data is not None:
                 if isinstance(validation_data, (tuple, list)) and not hasattr(validation_data, "__next__"):
@@ -376,10 +426,18 @@ class TrainingMixin:
                 else:
                     val = self.evaluate(validation_data, steps=validation_steps)
                 logs.update({"val_" + n: float(v) for n, v in zip(names, val)})
-            if verbose:
+            if dist is not None:
+                # the all-reduces above give every rank the same values already; the broadcast makes "identical logs" a
+                # property of the protocol rather than of the backend's reduction order: rank 0's numbers are THE logs
+                keys = list(logs)
+                vals = _host_collective([logs[k] for k in keys], "bcast", dist, src=0)
+                logs = {k: float(v) for k, v in zip(keys, vals)}
+            if verbose and rank == 0:
                 print("Epoch %d/%d - %.1fs - " % (ep + 1, epochs, time.time() - t0) + " - ".join("%s: %.4f" % kv for kv in logs.items()))
             for cb in cbs:
                 cb.on_epoch_end(ep, logs)
+            if dist is not None:  # a stop decided on ANY rank (a user callback with rank-local state) stops every rank
+                self.stop_training = bool(_host_collective([1.0 if self.stop_training else 0.0], "max", dist)[0] > 0.5)
             if self.stop_training:
                 break
         for cb in cbs:

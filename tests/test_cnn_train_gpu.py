@@ -346,8 +346,13 @@ def _cnn_dp_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the test box: gloo carries the CUDA tensor
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"  # RCCL when the box has a GPU per rank
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:  # one GPU on the test box: gloo carries the CUDA tensor
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     m, _ = _model(30, 68, seed=13)
     x, y = _batch(8, 30, 68, 21)
     sl = slice(rank * 4, rank * 4 + 4)

@@ -147,8 +147,15 @@ def _dp_worker(rank, world, port, q):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the test box: gloo carries the CUDA tensor
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # RCCL ("nccl") whenever the box has a GPU per rank -- the backend the product names; on a one-GPU box both ranks share
+    # the card and gloo carries the CUDA bucket tensor
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from sm_hpss_mtl_amd.model import B3MTL
     w, x, y, _, _ = _problem(3, 8, seed=9)
     m = B3MTL(n_feat=240, patch_size=68, n_classes=3, TR_STEPS=10)
