@@ -49,9 +49,12 @@ def mix_signals(x_sp, x_mu, target_db):
 # --------------------------------------------------------------------------------------------------
 def hann_window(win_length: int, n_fft: int) -> np.ndarray:
     """[librosa] get_window('hann', win_length, fftbins=True) -> periodic Hann, float64,
-    zero-padded symmetrically to n_fft (util.pad_center) when win_length < n_fft."""
-    n = np.arange(win_length, dtype=np.float64)
-    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+    zero-padded symmetrically to n_fft (util.pad_center) when win_length < n_fft.
+    Evaluated the way scipy.signal.get_window does it (general_cosine on linspace(-pi, pi, M + 1), last point dropped), so the
+    table is BIT-identical to the routine librosa delegates to (tests/test_oracle_pins.py); the textbook form
+    0.5 - 0.5 cos(2 pi n / M) differs from it by up to 8e-16."""
+    fac = np.linspace(-np.pi, np.pi, win_length + 1)
+    w = (0.5 + 0.5 * np.cos(fac))[:-1]
     if win_length < n_fft:
         lpad = (n_fft - win_length) // 2
         w = np.pad(w, (lpad, n_fft - win_length - lpad))
