@@ -56,6 +56,30 @@ struct BlockW {
     f32x4 b1lo, b1hi, b2lo, b2hi;
 };
 
+// The skewed task body takes its A operands through one of two providers with the same interface -- conv(g), g < 12: the
+// four operand slots {k-step 2g M-tile 0, 2g M-tile 1, 2g+1 M-tile 0, 2g+1 M-tile 1} of the dilated conv (k-step s = 8 tap + s8);
+// pw(g), g < 4: the same for the 1x1 conv; b1lo() .. b2hi(): the biases in accumulator layout.
+struct RegWeights {  // registers (kSkew: two BlockW sets per wave)
+    const BlockW &w;
+    __device__ __forceinline__ f32x4 conv(int g) const { return f32x4{w.wc[2 * g][0], w.wc[2 * g][1], w.wc[2 * g + 1][0], w.wc[2 * g + 1][1]}; }
+    __device__ __forceinline__ f32x4 pw(int g) const { return f32x4{w.wp[2 * g][0], w.wp[2 * g][1], w.wp[2 * g + 1][0], w.wp[2 * g + 1][1]}; }
+    __device__ __forceinline__ f32x4 b1lo() const { return w.b1lo; }
+    __device__ __forceinline__ f32x4 b1hi() const { return w.b1hi; }
+    __device__ __forceinline__ f32x4 b2lo() const { return w.b2lo; }
+    __device__ __forceinline__ f32x4 b2hi() const { return w.b2hi; }
+};
+struct LdsWeights {  // an LDS slot holding the packed block (kSkew16): one ds_read_b128 per group, conflict-free (lane-contiguous)
+    const float *blk;  // LDS address of the block: [16 groups][64 lanes][4] then b1[32], b2[32]
+    int lane, q;
+    __device__ __forceinline__ f32x4 at(int i) const { return *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(blk + i, 16)); }
+    __device__ __forceinline__ f32x4 conv(int g) const { return at(g * 256 + 4 * lane); }
+    __device__ __forceinline__ f32x4 pw(int g) const { return at((12 + g) * 256 + 4 * lane); }
+    __device__ __forceinline__ f32x4 b1lo() const { return at(4096 + 4 * q); }
+    __device__ __forceinline__ f32x4 b1hi() const { return at(4096 + 16 + 4 * q); }
+    __device__ __forceinline__ f32x4 b2lo() const { return at(4096 + 32 + 4 * q); }
+    __device__ __forceinline__ f32x4 b2hi() const { return at(4096 + 48 + 4 * q); }
+};
+
 // Block weights, LDS -> registers.  The workgroup's LDS copy of the block is staged by LDS-DMA one block ahead: every wave
 // needs the whole block, so the 16.6 KB come from L2 once per workgroup instead of once per wave.  Packed order
 // (pack_weights below): operand slot n = 2 s + mt (dilated conv, s < 24) or 48 + 2 e + mt (1x1 conv, e < 8) of lane l
@@ -260,11 +284,18 @@ __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int Z
 constexpr int kOneSet = 0;   // barrier per block, one weight register set read from the LDS slot at the top of the block (9..12 waves)
 constexpr int kPrefetch = 1; // barrier per block, two register sets (8 waves)
 constexpr int kSkew = 2;     // no barrier: (block, tile) tasks taken from a counter by 8 waves, tile-level completion flags
+// The same task schedule on SIXTEEN waves (four per SIMD, 128 VGPRs each): the block weights are not held in registers (two sets
+// of 80 made the 8-wave build a 225-VGPR kernel, two waves per SIMD, whose product and non-product sections interleave at only
+// two thirds of the matrix pipe's rate) but stay in LDS -- a ring of four block slots filled by LDS-DMA two blocks ahead -- and
+// every product group reads its A operands from there (one ds_read_b128 per four operand slots).  Same instructions in the same
+// order on the same values: outputs are bit-identical to the other schedules.  Inference only.
+constexpr int kSkew16 = 3;
+constexpr int kWeightRing = 4;   // LDS block slots of kSkew16 (blocks b - 1 .. b + 2 can be live at once)
 constexpr int kSkewSpinLimit = 1 << 22;  // polls before a wave gives up on a dependency (never reached; the grid must drain)
 
 // TRACE: tools/trace_model.py only -- s_memtime / s_memrealtime stamps into a.trace; every stamp compiles out otherwise
 template <bool TRAIN, int MODE, bool TRACE = false>
-__global__ void __launch_bounds__(MODE == kOneSet ? 768 : 512)
+__global__ void __launch_bounds__(MODE == kOneSet ? 768 : (MODE == kSkew16 ? 1024 : 512))
 b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__restrict__ W0, const float *__restrict__ Wb,
                      const float *__restrict__ WhA, const float *__restrict__ hp, float *__restrict__ trunk,
                      float *__restrict__ out, TrainIO tio) {
@@ -287,7 +318,10 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     // Layer 0 is an HBM stream (261 KB of X per workgroup): every lane issues ALL loads of its column
     // tiles first (registers are free: the block weights are not loaded yet), so one HBM latency is
     // exposed instead of one per k-group.  A operands are staged once in LDS and shared by all tiles.
-    constexpr int kMaxU = 3;    // column tiles per wave (17 tiles over 8 waves)
+    // column tiles per wave whose rows are all in flight at once: 17 tiles over 8 waves -> 3; the 16-wave build has 128 VGPRs and
+    // takes its (at most two) tiles one after the other, four waves per SIMD covering each other's latency
+    constexpr int kMaxU = MODE == kSkew16 ? 1 : 3;
+    constexpr int kRoundsU = MODE == kSkew16 ? 2 : 1;
     constexpr int kFQ4 = 15;    // float4 groups per lane for n_feat = 240
     {
         float *w0s = xb;  // layer-0 A operands live in the not-yet-used activation buffer
@@ -320,21 +354,22 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                     }
                 }
             }
-        } else if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kMaxU * nw) {
+        } else if (a.vec_ok && a.FQ == 4 * kFQ4 && units <= kRoundsU * kMaxU * nw) {
+            for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = W0[i];
+            for (int rnd = 0; rnd < kRoundsU; ++rnd) {
             f32x4 xr[kMaxU][kFQ4];
 #pragma unroll
             for (int i = 0; i < kMaxU; ++i) {
-                const int u = min(wave + i * nw, units - 1);
+                const int u = min(wave + (rnd * kMaxU + i) * nw, units - 1);
                 const int Rc = min(16 * u + j, GR - 1);
                 const float *xrow = X + ((size_t)n0 * T + Rc) * a.F + (size_t)q * a.FQ;
 #pragma unroll
                 for (int g = 0; g < kFQ4; ++g) xr[i][g] = *reinterpret_cast<const f32x4 *>(xrow + 4 * g);
             }
-            for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = W0[i];
-            __syncthreads();
+            if (rnd == 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < kMaxU; ++i) {
-                const int u = wave + i * nw;
+                const int u = wave + (rnd * kMaxU + i) * nw;
                 if (u < units) {  // wave-uniform
                     f32x4 c0 = bl, c1 = bh;
 #pragma unroll
@@ -349,6 +384,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                     *reinterpret_cast<f32x4 *>(dst) = c0;
                     *reinterpret_cast<f32x4 *>(dst + 16) = c1;
                 }
+            }
             }
         } else {
             for (int i = threadIdx.x; i < nW0; i += blockDim.x) w0s[i] = W0[i];
@@ -419,11 +455,14 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         xin = xout;
         xout = tmp;
     };
-    if (MODE != kSkew && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+    if (MODE != kSkew && MODE != kSkew16 && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
         a.trace[4 * (2000 + blockIdx.x)] = __builtin_amdgcn_s_memtime();
         a.trace[4 * (2000 + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    if constexpr (MODE == kSkew) {
+    static_assert(!(TRAIN && MODE == kSkew16), "the 16-wave schedule is built for inference");
+    // completion flags of the skewed schedules: kSkew keeps them in the (unused) weight slots, kSkew16 behind its weight ring
+    float *flagbase = ws + (MODE == kSkew16 ? (size_t)kWeightRing * kBlockFloats : 0);
+    if constexpr (MODE == kSkew || MODE == kSkew16) {
         // Skewed schedule.  Task n = (block n / units, tile n % units) belongs to wave n % 8, i.e. SIMD n % 4: every SIMD gets a
         // quarter of the block x tile grid (17 tiles per block are 5-4-4-4 under a barrier per block, 4.25 each here).  A task
         // starts when the tiles it touches have finished the previous block -- done[x] counts the blocks tile x has completed:
@@ -443,10 +482,36 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         //     publish, poll and read in sequence after the task.
         // (an LDS-typed pointer: a generic volatile access would be a flat load that waits for the weight loads in flight)
         typedef __attribute__((address_space(3))) volatile int lds_vint;
-        lds_vint *done = (lds_vint *)(ws);  // [0..31] per tile, [63] = a wave gave up waiting
-        if (threadIdx.x < 64) done[threadIdx.x] = threadIdx.x == 62 ? nw : 0;  // [62]: the task counter
+        // [0..31] per tile, [56..59] (kSkew16) the block whose weights have landed in ring slot 0..3, [62] the task counter,
+        // [63] = a wave gave up waiting
+        lds_vint *done = (lds_vint *)(flagbase);
+        if (threadIdx.x < 64) {
+            int v = threadIdx.x == 62 ? nw : 0;
+            if (MODE == kSkew16 && threadIdx.x >= 56 && threadIdx.x < 60)  // blocks 0 and 1 are staged below, before the barrier
+                v = (threadIdx.x - 56 < 2 && threadIdx.x - 56 < a.n_blocks) ? threadIdx.x - 56 : -1;
+            done[threadIdx.x] = v;
+        }
+        // kSkew16: block blk -> ring slot blk % 4 by LDS-DMA, 1 KiB per wave instruction (17 for the 16.25 KiB of a block),
+        // shared out over waves w0, w0 + nwv, ...
+        auto stage_ring = [&](int blk, int w0, int nwv) {
+            const char *src = reinterpret_cast<const char *>(Wb + (size_t)blk * kBlockFloats);
+            char *dst = reinterpret_cast<char *>(ws + (size_t)(blk & (kWeightRing - 1)) * kBlockFloats);
+            constexpr int nch = kBlockFloats * 4 / 16;
+            for (int i = w0; i * 64 < nch; i += nwv) {
+                const int c = i * 64 + lane;
+                if (c < nch)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 16),
+                                                     (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
+            }
+        };
         BlockW w0, w1;
-        load_block_lds(w0, Wb, lane, q);
+        if constexpr (MODE == kSkew) {
+            load_block_lds(w0, Wb, lane, q);
+        } else {
+            stage_ring(0, wave, nw);
+            if (a.n_blocks > 1) stage_ring(1, wave, nw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed; the barrier covers the others'
+        }
         __syncthreads();  // x0, zero rows, flags
         save_acts(xin, 0);  // (training) the input of block 0; every later slot is written by the task that produces it
         // save_acts copies rows of xa striding over ALL tiles, and block-1 tasks write their outputs back into xa: the flags only
@@ -530,11 +595,16 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             const unsigned ok = (unsigned)__ballot(have >= blk);
             return (ok & mask) == mask;
         };
+        // (kSkew16) the weights of block blk have landed in their ring slot: flag word 56 + slot, sampled with the tile flags
+        auto w_ready = [&](int have, int blk) {
+            if constexpr (MODE != kSkew16) return true;
+            return __builtin_amdgcn_readlane(have, 56 + (blk & (kWeightRing - 1))) >= blk;
+        };
         auto wait_for = [&](int blk, int u) {
-            const unsigned mask = dep_mask(blk, u);
+            const unsigned mask = blk > 0 ? dep_mask(blk, u) : 0u;
             for (int spins = 0;; ++spins) {
                 const int have = done[lane];
-                if (stands(have, blk, mask)) break;
+                if (stands(have, blk, mask) && w_ready(have, blk)) break;
                 if (__any(lane == 63 && have != 0)) break;
                 if (spins > a.spin_limit) {
                     if (lane == 0) done[63] = 1;
@@ -552,7 +622,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         Ops cur;
         bool have_cur = n < n_tasks;
         if (have_cur) {
-            if (blk > 0) wait_for(blk, u);  // fewer tiles than waves: a wave's first task may sit in a later block
+            if (blk > 0) wait_for(blk, u);  // fewer tiles than waves: a wave's first task may sit in a later block (kSkew16: + its weights)
             issue_ops(cur, blk, u);
         }
         auto publish = [&]() {
@@ -563,18 +633,32 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 pend_u = -1;
             }
         };
-        auto tasks = [&](int blk0, const BlockW &w) {
-            while (have_cur && blk == blk0) {
+        // (kSkew16) a block this wave has put on its way into the ring (stage_ring, below) and not yet named in its slot's flag word
+        int staged = -1;
+        auto publish_staged = [&]() {
+            if constexpr (MODE == kSkew16) {
+                if (staged >= 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed in LDS
+                    if (lane == 0) done[56 + (staged & (kWeightRing - 1))] = staged;
+                    staged = -1;
+                }
+            }
+        };
+        auto one_task = [&](const auto &w) {
+            {
                 const int dsti = __mul24(16 * u + j, SX) + ((blk & 1) ? 0 : xb_off) + 4 * q;  // this lane's output row
                 const bool stamp = tracing && (a.tune & 128) && blockIdx.x == 0;
                 unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
                 if (stamp) st[0] = __builtin_amdgcn_s_memtime();
-                f32x4 acc0 = w.b1lo, acc1 = w.b1hi;
-                auto half_tap = [&](int tp, int h) {
+                f32x4 acc0 = w.b1lo(), acc1 = w.b1hi();
+                auto half_tap = [&](int tp, int h) {  // k-steps 8 tp + 4 h + s4, s4 = 0..3 = operand groups 4 tp + 2 h, + 1
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        acc0 = mfma4(w.wc[tp * 8 + 4 * h + s4][0], cur.b[tp][h][s4], acc0);
-                        acc1 = mfma4(w.wc[tp * 8 + 4 * h + s4][1], cur.b[tp][h][s4], acc1);
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const f32x4 wv = w.conv(4 * tp + 2 * h + g2);
+                        acc0 = mfma4(wv[0], cur.b[tp][h][2 * g2], acc0);
+                        acc1 = mfma4(wv[1], cur.b[tp][h][2 * g2], acc1);
+                        acc0 = mfma4(wv[2], cur.b[tp][h][2 * g2 + 1], acc0);
+                        acc1 = mfma4(wv[3], cur.b[tp][h][2 * g2 + 1], acc1);
                     }
                 };
                 half_tap(1, 0);
@@ -590,6 +674,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                         *reinterpret_cast<f32x4 *>(up + 16) = acc1;
                     }
                 }
+                // (kSkew16) the block staged at the top of this task has had the dilated-conv products' time to land: name it BEFORE this
+                // wave can wait for anything -- with few tiles per block its own next task may need that very block
+                publish_staged();
                 // take the next task and sample the flags; both are judged behind the epilogue
                 if (stamp) st[2] = __builtin_amdgcn_s_memtime();
                 int taken = 0;
@@ -605,13 +692,16 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 }
                 mx = quad_max(mx);
                 const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
-                f32x4 o0 = cur.r0 + w.b2lo, o1 = cur.r1 + w.b2hi;
+                f32x4 o0 = cur.r0 + w.b2lo(), o1 = cur.r1 + w.b2hi();
                 asm volatile("" : "+v"(o0), "+v"(o1));  // the sums now: the residual registers are about to be reloaded
                 int arow = 0;
                 if constexpr (TRAIN) {  // normalised and masked now: issue_ops below reloads cur (the next task's mask)
                     acc0 = acc0 * inv * cur.dm0, acc1 = acc1 * inv * cur.dm1;
                     arow = cur.arow;
                 }
+                // the 1x1 conv's operand groups now (LdsWeights: four ds_read_b128 in front of the next task's operand reads -- LDS
+                // returns in order, the products must not queue behind those; RegWeights: nothing)
+                const f32x4 pwv[4] = {w.pw(0), w.pw(1), w.pw(2), w.pw(3)};
                 const int nn = __builtin_amdgcn_readfirstlane(taken);
                 if (stamp) st[3] = __builtin_amdgcn_s_memtime();
                 // The operand registers are free: the next task's operands are read under the 1x1-conv products.  Unconditionally
@@ -620,20 +710,26 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 const bool have_next = nn < n_tasks;
                 const int nnc = min(nn, n_tasks - 1);
                 const int nblk = (nnc * m_units) >> 16, nu = nnc - nblk * units;
-                const bool fetched = have_next && (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu)));
+                const bool fetched = have_next && (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu))) && w_ready(have, nblk);
                 issue_ops(cur, nblk, nu);
                 if (stamp) st[4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y0 = TRAIN ? acc0[r] : acc0[r] * inv;  // channel 4q + r
-                    o0 = mfma4(w.wp[r][0], y0, o0);
-                    o1 = mfma4(w.wp[r][1], y0, o1);
+                for (int g2 = 0; g2 < 2; ++g2) {  // 1x1-conv k-steps r = 2 g2, 2 g2 + 1 on acc0: channels 4q + r
+                    const f32x4 wv = pwv[g2];
+                    const float ya = TRAIN ? acc0[2 * g2] : acc0[2 * g2] * inv, yb = TRAIN ? acc0[2 * g2 + 1] : acc0[2 * g2 + 1] * inv;
+                    o0 = mfma4(wv[0], ya, o0);
+                    o1 = mfma4(wv[1], ya, o1);
+                    o0 = mfma4(wv[2], yb, o0);
+                    o1 = mfma4(wv[3], yb, o1);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y1 = TRAIN ? acc1[r] : acc1[r] * inv;  // channel 16 + 4q + r
-                    o0 = mfma4(w.wp[4 + r][0], y1, o0);
-                    o1 = mfma4(w.wp[4 + r][1], y1, o1);
+                for (int g2 = 0; g2 < 2; ++g2) {  // ... and on acc1: channels 16 + 4q + r
+                    const f32x4 wv = pwv[2 + g2];
+                    const float ya = TRAIN ? acc1[2 * g2] : acc1[2 * g2] * inv, yb = TRAIN ? acc1[2 * g2 + 1] : acc1[2 * g2 + 1] * inv;
+                    o0 = mfma4(wv[0], ya, o0);
+                    o1 = mfma4(wv[1], ya, o1);
+                    o0 = mfma4(wv[2], yb, o0);
+                    o1 = mfma4(wv[3], yb, o1);
                 }
                 *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti, 16)) = o0;
                 *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(lds + dsti + 16, 16)) = o1;
@@ -664,16 +760,45 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 n = nn, blk = nblk, u = nu;
             }
         };
-        // the weight loads are unconditional (past the last block: the last block again) so that the number of loads in flight
-        // behind a register set is the same on every path -- the compiler then waits for exactly that set (vmcnt(20 + x))
-        // instead of for the youngest loads of the shortest path, i.e. for the prefetch it has just issued
-        const int last = a.n_blocks - 1;
-        for (int b0 = 0; b0 < a.n_blocks; b0 += 2) {
-            load_block_lds(w1, Wb + (size_t)min(b0 + 1, last) * kBlockFloats, lane, q);
-            tasks(b0, w0);
-            if (b0 + 1 >= a.n_blocks) break;
-            load_block_lds(w0, Wb + (size_t)min(b0 + 2, last) * kBlockFloats, lane, q);
-            tasks(b0 + 1, w1);
+        if constexpr (MODE == kSkew) {
+            // the weight loads are unconditional (past the last block: the last block again) so that the number of loads in flight
+            // behind a register set is the same on every path -- the compiler then waits for exactly that set (vmcnt(20 + x))
+            // instead of for the youngest loads of the shortest path, i.e. for the prefetch it has just issued
+            const int last = a.n_blocks - 1;
+            for (int b0 = 0; b0 < a.n_blocks; b0 += 2) {
+                load_block_lds(w1, Wb + (size_t)min(b0 + 1, last) * kBlockFloats, lane, q);
+                while (have_cur && blk == b0) one_task(RegWeights{w0});
+                if (b0 + 1 >= a.n_blocks) break;
+                load_block_lds(w0, Wb + (size_t)min(b0 + 2, last) * kBlockFloats, lane, q);
+                while (have_cur && blk == b0 + 1) one_task(RegWeights{w1});
+            }
+        } else {
+            // kSkew16.  The wave that runs tile 0 of block b brings block b + 2 into the ring: slot (b + 2) % 4 last held block
+            // b - 2, whose readers are the tasks of block b - 2 -- all long finished (they lie 34+ tasks back), which is checked,
+            // not assumed.  The DMA travels while the wave runs its task; behind the task the wave drains it and names the block
+            // in the slot's flag word.  Consumers see that word in the flag sample they take anyway (w_ready).
+            while (have_cur) {
+                if (u == 0 && blk + 2 < a.n_blocks) {  // (wave-uniform)
+                    if (blk >= 2) {
+                        // "a wave never waits while it holds an unpublished flag": this wave's previous task may be one of block
+                        // blk - 2 (a slow wave takes task (blk, 0) from as far back as that), and its own tile is in the set below
+                        publish();
+                        for (int spins = 0;; ++spins) {
+                            const int have = done[lane];
+                            if (stands(have, blk - 1, all_tiles)) break;
+                            if (__any(lane == 63 && have != 0)) break;
+                            if (spins > a.spin_limit) {
+                                if (lane == 0) done[63] = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    staged = blk + 2;
+                    stage_ring(staged, 0, 1);
+                }
+                one_task(LdsWeights{ws + (size_t)(blk & (kWeightRing - 1)) * kBlockFloats, lane, q});
+            }
         }
         publish();
         xin = (a.n_blocks & 1) ? xb : xa;
@@ -722,12 +847,12 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             }
         }
     }
-    if (MODE != kSkew && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
+    if (MODE != kSkew && MODE != kSkew16 && tracing && blockIdx.x < 1024 && threadIdx.x == 0) {
         a.trace[4 * (2000 + blockIdx.x) + 2] = __builtin_amdgcn_s_memtime();
         a.trace[4 * (2000 + blockIdx.x) + 3] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
-    if constexpr (MODE != kSkew) save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
+    if constexpr (MODE != kSkew && MODE != kSkew16) save_acts(xin, a.n_blocks);  // pre-relu TCN output (training)
     if constexpr (TRAIN) __syncthreads();
     // final relu in place (xin = TCN output); optional tap to global as (N, T, 32) == Keras Flatten order
     for (int i = threadIdx.x; i < GR * (C / 4); i += blockDim.x) {
@@ -741,7 +866,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     __syncthreads();
 
     bool gave_up = false;
-    if constexpr (MODE == kSkew) gave_up = ((__attribute__((address_space(3))) volatile int *)(ws))[63] != 0;  // the heads do not touch ws
+    if constexpr (MODE == kSkew || MODE == kSkew16) gave_up = ((__attribute__((address_space(3))) volatile int *)(flagbase))[63] != 0;  // the heads do not touch it
     dense_and_heads<TRAIN>(a, xin, xout, WhA, hp, out, tio, n0, g_here);
     if (tracing && blockIdx.x < 256 && threadIdx.x == 0) a.trace[4 * 3000 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if (gave_up) {  // a dependency never arrived: the outputs are not results -- say so in the model's error word
@@ -970,6 +1095,15 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     if (const char *ev = getenv("SMH_TCN_SKEW")) skew = atoi(ev) == 2 ? skew_ok : (skew && atoi(ev) != 0);
     if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
     if (skew) nwaves = std::min(nwaves, 8);
+    // The 16-wave form of the skew schedule (weights in an LDS ring, four waves per SIMD): inference, when its ring fits beside
+    // the activations.  OPT-IN (SMH_TCN_SKEW16=1): measured on the bench shape it runs 135.7-136.2 us against 133.6-134.2 us for the
+    // 8-wave form (tools/gpu/r3_net.sh) -- twice the waves per SIMD buy nothing, i.e. the loop is not short of waves to hide
+    // latency behind: exact-f32 MFMA and the VALU work of the epilogues do not overlap.  Kept as the measured
+    // experiment and as a third implementation the schedule-agreement test holds bit-identical to the other two.
+    const size_t lds16 = sizeof(float) * (2 * (size_t)(a.GRP + 1) * SX + (size_t)kWeightRing * kBlockFloats + 64);
+    bool skew16 = false;
+    if (const char *ev = getenv("SMH_TCN_SKEW16")) skew16 = atoi(ev) != 0 && skew && !tio && !a.trace && lds16 <= 156 * 1024;
+    if (skew16) nwaves = 16, lds = lds16;
     const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
     TrainIO io{nullptr, nullptr, nullptr, nullptr};
     if (tio) io = *tio;
@@ -988,6 +1122,8 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
         if (skew) SMH_LAUNCH_FWD(false, kSkew, true);
         else if (prefetch) SMH_LAUNCH_FWD(false, kPrefetch, true);
         else SMH_LAUNCH_FWD(false, kOneSet, true);
+    } else if (skew16) {
+        SMH_LAUNCH_FWD(false, kSkew16, false);
     } else if (skew) {
         SMH_LAUNCH_FWD(false, kSkew, false);
     } else {

@@ -348,13 +348,18 @@ def test_b3mtl_block_schedules_agree(W, N, monkeypatch):
     m.set_weights_dict(w)
     x = dev(np.random.default_rng(3).standard_normal((N, W, 240)).astype(np.float32))
     outs = {}
-    for skew in ("2", "0"):  # 2: the skew schedule whenever it can run (by default only where it is the faster one)
-        monkeypatch.setenv("SMH_TCN_SKEW", skew)
+    # 2: the skew schedule whenever it can run (by default only where it is the faster one); "16": its 16-wave form with the
+    # block weights in an LDS ring instead of registers (opt-in, SMH_TCN_SKEW16=1)
+    for skew in ("2", "0", "16"):
+        monkeypatch.setenv("SMH_TCN_SKEW", "2" if skew == "16" else skew)
+        monkeypatch.setenv("SMH_TCN_SKEW16", "1" if skew == "16" else "0")
         trunk = torch.empty((N, W, 32), device="cuda")
         outs[skew] = (host(m.forward_device(x, trunk=trunk)), host(trunk))
-    # bit for bit: both add the same products in the same order (centre tap first), so a patch's outputs do not depend on the
+        m.check_status()
+    # bit for bit: all add the same products in the same order (centre tap first), so a patch's outputs do not depend on the
     # schedule its batch size selects
     assert np.array_equal(outs["2"][0], outs["0"][0]) and np.array_equal(outs["2"][1], outs["0"][1])
+    assert np.array_equal(outs["16"][0], outs["0"][0]) and np.array_equal(outs["16"][1], outs["0"][1])
     sel = np.unique(np.r_[0:min(4, N), max(0, N - 4):N])
     ref = np.concatenate(b3_mtl.forward(host(x)[sel], w, n_classes=3), axis=1)
     for skew in ("2", "0"):
