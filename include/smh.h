@@ -370,6 +370,12 @@ size_t smh_trainer_bucket_floats(const smh_trainer *t);
 int smh_trainer_copy_state(smh_trainer *dst, const smh_trainer *src, void *stream);
 /* zero the optimiser state (what compiling a Keras model with a new optimiser does) */
 int smh_trainer_reset_state(smh_trainer *t, void *stream);
+/* Deterministic weight gradients (off by default).  The backward kernels combine the workgroups' contributions with float
+ * atomics, whose arrival order -- hence the last bits of a gradient -- changes from run to run.  on = 1: contributions are
+ * rounded to a 2^-36 grid and summed in 64-bit integers (integer atomics: order-independent), so two runs of the same step give
+ * bit-identical gradients, data-parallel replicas stay comparable run to run, and a result can be reproduced.  Costs one extra
+ * pass over the gradient and 8-byte atomics (tools/bench_train.py --deterministic states the step time). */
+int smh_trainer_set_deterministic(smh_trainer *t, int on, void *stream);
 /* General optimiser step.  optimizer 0 = SGD (beta1 = momentum; what smh_trainer_apply_sgd_f32 calls), 1 = Adam,
  * 2 = Nadam as tf.keras 2.x implements it (momentum schedule u_t = beta1 (1 - 0.5 * 0.96^(0.004 t)); the optimiser of the
  * single-head fine-tuning in DAFx12_Speech_Music_Detection_B3_MTL_v2.py:524-526).  active_mask selects the tensors that

@@ -115,6 +115,7 @@ SIGNATURES = {
     "smh_trainer_bucket_floats": (_sz, [_vp]),
     "smh_trainer_copy_state": (_i, [_vp, _vp, _vp]),
     "smh_trainer_reset_state": (_i, [_vp, _vp]),
+    "smh_trainer_set_deterministic": (_i, [_vp, _i, _vp]),
     "smh_trainer_apply_f32": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint, _vp]),
 }
 

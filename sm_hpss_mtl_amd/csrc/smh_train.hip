@@ -86,7 +86,11 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
     extern __shared__ __attribute__((aligned(16))) float stage[];
     __shared__ float s_mean[64], s_inv[64];
     __shared__ float red[16][kQ], tot[kQ];  // per-wave accumulator rows (blockDim.x <= 1024), their totals
+    // non-STAGED path only: the Dense(16) bias gradients, summed on a 2^-36 grid with integer atomics (order-independent: a float
+    // ds_add here made that tensor differ from run to run for batches too large for the LDS tile)
+    __shared__ unsigned long long dbq[64];
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (!STAGED && tid < 64) dbq[tid] = 0ull;
     float *row = red[tid >> 6];
     unsigned long long tk[8];
     int ntk = 0;
@@ -270,7 +274,7 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
             const float xhat = (pre[(size_t)n * kPS + ncls + j] - s_mean[j]) * s_inv[j];
             const float d = s_inv[j] / (float)N * ((float)N * dxh[(size_t)n * kPS + j] - tot[Q_SUM1 + j] - xhat * tot[Q_SUM2 + j]);
             dpre[(size_t)n * kPS + ncls + j] = d;
-            atomicAdd(&red[0][Q_DBIAS + j], d);  // lanes of one wave hold different units here
+            atomicAdd(&dbq[j - j_lo], (unsigned long long)__float2ll_rn(d * 68719476736.0f));  // lanes of one wave hold different units here
         }
     }
     stamp();  // C
@@ -319,6 +323,10 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
             }
     }
     stamp();  // D (+ copy-out)
+    if constexpr (!STAGED) {
+        __syncthreads();
+        if (tid < j_hi - j_lo) red[0][Q_DBIAS + j_lo + tid] = (float)((double)(long long)dbq[tid] * (1.0 / 68719476736.0));
+    }
     totals();
     // E: gradients of the small tensors (this workgroup is their only writer) and the losses
     for (int j = j_lo + tid; j < j_hi; j += nt) {
@@ -355,7 +363,31 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
 }
 
+// Weight-gradient accumulation.  Default: hardware float atomics (global_atomic_add_f32, -munsafe-fp-atomics) -- fastest, but the
+// order in which the workgroups' contributions meet is not fixed, so a gradient's last bits differ from run to run.
+// DETERMINISTIC mode (smh_trainer_set_deterministic): every contribution is rounded to a 2^-36 grid and added to a 64-bit
+// integer accumulator with an integer atomic.  Integer addition is associative, so the sum does not depend on arrival order:
+// two runs of the same step give the same bits.  Range +-2^27 per tensor element, resolution 1.5e-11 (a float32 sum of these
+// gradients resolves ~1e-8 at best); det_finalize_kernel converts the accumulators back into the float gradient and clears them.
+constexpr float kDetScale = 68719476736.0f;          // 2^36
+constexpr double kDetInvScale = 1.0 / 68719476736.0;
+__device__ __forceinline__ void gadd(float *grad, unsigned long long *gq, size_t i, float v) {
+    if (gq) atomicAdd(gq + i, (unsigned long long)__float2ll_rn(v * kDetScale));  // (uniform branch)
+    else atomicAdd(grad + i, v);
+}
+__global__ void det_finalize_kernel(unsigned long long *__restrict__ gq, float *__restrict__ grad, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const long long q = (long long)gq[i];
+        if (q != 0) {
+            grad[i] += (float)((double)q * kDetInvScale);  // grad[i] is 0 here (cleared at the top of the step) for every atomically summed tensor
+            gq[i] = 0ull;
+        }
+    }
+}
+
 struct BwdArgs {
+    unsigned long long *gq;  // deterministic mode: the fixed-point accumulators (n_params), else nullptr
     int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
     int stamps;  // tools only (SMH_BWD_STAMPS): workgroup 0 prints the time its phases took, summed over the blocks
     int use_wt;  // VALU kernel: keep transposed LDS copies of the block kernels (0 for patches so long that they do not fit)
@@ -400,14 +432,14 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
         const float *dp = dps + g * kPS;
         for (int o = 0; o < a.n_classes; ++o) {
             acc = fmaf(dp[o], flatw[a.off.c3_k + k * a.n_classes + o], acc);
-            if (fl != 0.f) atomicAdd(&grad[a.off.c3_k + k * a.n_classes + o], fl * dp[o]);
+            if (fl != 0.f) gadd(grad, a.gq, a.off.c3_k + k * a.n_classes + o, fl * dp[o]);
         }
         for (int h = 0; h < a.n_heads; ++h) {
             const size_t base = a.off.head[h] + k * kHidden;
             for (int j = 0; j < kHidden; ++j) {
                 const float d = dp[a.n_classes + h * kHidden + j];
                 acc = fmaf(d, flatw[base + j], acc);
-                if (fl != 0.f) atomicAdd(&grad[base + j], fl * d);
+                if (fl != 0.f) gadd(grad, a.gq, base + j, fl * d);
             }
         }
         G[R * kBS + c] = xpre > 0.f ? acc : 0.f;
@@ -473,8 +505,8 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
                 acc = fmaf(Y[R * kBS + c], gv, acc);
                 accb += gv;
             }
-            atomicAdd(&grad[o_k2 + i], acc);
-            if (c == 0) atomicAdd(&grad[o_b2 + co], accb);
+            gadd(grad, a.gq, o_k2 + i, acc);
+            if (c == 0) gadd(grad, a.gq, o_b2 + co, accb);
         }
         __syncthreads();
         // dyn = g @ W2^T (masked) ; norm backward ; du = dr * (u > 0)  -> U
@@ -513,8 +545,8 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
                 accb += duv;
                 if (t + off >= 0 && t + off < T) acc = fmaf(Xs[(R + off) * kBS + c], duv, acc);
             }
-            atomicAdd(&grad[o_k1 + i], acc);
-            if (tap == 0 && c == 0) atomicAdd(&grad[o_b1 + co], accb);
+            gadd(grad, a.gq, o_k1 + i, acc);
+            if (tap == 0 && c == 0) gadd(grad, a.gq, o_b1 + co, accb);
         }
         __syncthreads();
         // g[R][c] += sum_tap sum_co du[R - off][co] W1[tap][c][co]
@@ -544,8 +576,8 @@ tcn_backward_kernel(BwdArgs a, const float *__restrict__ X, const float *__restr
             acc = fmaf(X[((size_t)n0 * T + R) * a.F + f], gv, acc);
             accb += gv;
         }
-        atomicAdd(&grad[a.off.w0_k + i], acc);
-        if (f == 0) atomicAdd(&grad[a.off.w0_b + c], accb);
+        gadd(grad, a.gq, a.off.w0_k + i, acc);
+        if (f == 0) gadd(grad, a.gq, a.off.w0_b + c, accb);
     }
 }
 
@@ -717,10 +749,10 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
             const TileJob &jb = i ? j1 : j0;
             const f32x4 v = acc[i][0] + acc[i][1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&grad[jb.gbase + (unsigned)((16 * jb.mt + 4 * q + r) * C + 16 * jb.nt + j)], v[r]);
+            for (int r = 0; r < 4; ++r) gadd(grad, a.gq, jb.gbase + (unsigned)((16 * jb.mt + 4 * q + r) * C + 16 * jb.nt + j), v[r]);
             if (jb.with_bias) {  // (uniform) column sums: over this lane's rows, then over the four lane groups
                 const float cs = quad_reduce(bsum[i], [](float x, float y) { return x + y; });
-                if (q == 0) atomicAdd(&grad[jb.gbias + 16 * jb.nt + j], cs);
+                if (q == 0) gadd(grad, a.gq, jb.gbias + 16 * jb.nt + j, cs);
             }
         }
     };
@@ -962,12 +994,12 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         }
         acc += acc2;
         if (bias) {
-            if (q == 0) atomicAdd(&grad[a.off.w0_b + 16 * nt_ + j], acc[0]);
+            if (q == 0) gadd(grad, a.gq, a.off.w0_b + 16 * nt_ + j, acc[0]);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ff = 16 * mt + 4 * q + r;
-                if (ff < a.F) atomicAdd(&grad[a.off.w0_k + (size_t)ff * C + 16 * nt_ + j], acc[r]);
+                if (ff < a.F) gadd(grad, a.gq, a.off.w0_k + (size_t)ff * C + 16 * nt_ + j, acc[r]);
             }
         }
     }
@@ -1013,7 +1045,7 @@ __global__ void dwh_kernel(BwdArgs a, const float *__restrict__ acts, const floa
         const float fl = fmaxf(acts[((size_t)b * nslot + a.n_blocks) * a.D + k], 0.f);
         acc = fmaf(fl, dpre[(size_t)b * kPS + o0 + o], acc);
     }
-    atomicAdd(grad + (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + i, acc);
+    gadd(grad, a.gq, (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + i, acc);
 }
 
 // The same rank-N update on the matrix cores: dWh (D x 51) = relu(X)^T (D x N) . dpre (N x 51).  One wave = one 16 x 16 tile
@@ -1059,9 +1091,9 @@ __global__ void __launch_bounds__(256) dwh_mfma_kernel(BwdArgs a, const float *_
     }
     acc0 += acc1;
     if (col_ok) {
-        float *g = grad + (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + (size_t)(k0 + 4 * kq) * ocount + i;
+        const size_t g = (grp == 0 ? a.off.c3_k : a.off.head[grp - 1]) + (size_t)(k0 + 4 * kq) * ocount + i;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(g + (size_t)r * ocount, acc0[r]);
+        for (int r = 0; r < 4; ++r) gadd(grad, a.gq, g + (size_t)r * ocount, acc0[r]);
     }
 }
 
@@ -1213,6 +1245,7 @@ struct smh_trainer {
     // ONE bucket [gradient (n_params) | BatchNorm batch statistics (kMaxHeads * 32)]: what data-parallel training all-reduces
     float *d_grad = nullptr, *d_bnstat = nullptr;
     float *d_vel = nullptr, *d_s2 = nullptr;  // optimiser state: momentum / first moment, second moment
+    unsigned long long *d_gq = nullptr;       // deterministic mode: fixed-point gradient accumulators (n_params), else nullptr
     float *d_sumsq = nullptr, *d_scratch_out = nullptr;
     float *d_upre = nullptr;  // (max_batch, n_blocks, T, 32): TrainIO::upre
     double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
@@ -1295,10 +1328,33 @@ extern "C" void smh_trainer_destroy(smh_trainer *t) {
         (void)hipFree(p);
     (void)hipFree(t->d_segs);
     (void)hipFree(t->d_l2part);
+    (void)hipFree(t->d_gq);
     delete t;
 }
 
 extern "C" float *smh_trainer_grad_ptr(smh_trainer *t) { return t ? t->d_grad : nullptr; }
+
+// deterministic mode: fixed-point accumulators -> the float gradient (after the last backward kernel of a step)
+static int det_finalize(smh_trainer *t, hipStream_t st) {
+    if (!t->d_gq) return SMH_OK;
+    const size_t n = t->m->n_params;
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t->d_gq, t->d_grad, n);
+    return smh::launch_status("det_finalize_kernel");
+}
+
+extern "C" int smh_trainer_set_deterministic(smh_trainer *t, int on, void *stream) {
+    SMH_REQUIRE(t, "smh_trainer_set_deterministic: null trainer");
+    hipStream_t st = (hipStream_t)stream;
+    if (on && !t->d_gq) {
+        SMH_CHECK_HIP(hipMalloc((void **)&t->d_gq, t->m->n_params * sizeof(unsigned long long)));
+        SMH_CHECK_HIP(hipMemsetAsync(t->d_gq, 0, t->m->n_params * sizeof(unsigned long long), st));
+    } else if (!on && t->d_gq) {
+        SMH_CHECK_HIP(hipStreamSynchronize(st));
+        (void)hipFree(t->d_gq);
+        t->d_gq = nullptr;
+    }
+    return SMH_OK;
+}
 
 extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
                                   const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream) {
@@ -1331,6 +1387,7 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
                             reinterpret_cast<unsigned *>(t->d_dxh + (size_t)t->max_batch * kPS), st);
     if (rc) return rc;
     BwdArgs ba;
+    ba.gq = t->d_gq;  // nullptr unless smh_trainer_set_deterministic(t, 1)
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.use_wt = 1;
     ba.stamps = getenv("SMH_BWD_STAMPS") ? 1 : 0;
@@ -1362,11 +1419,13 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
         if (getenv("SMH_DWH_VALU")) {  // the one-thread-per-element kernel (a second implementation for the tests)
             hipLaunchKernelGGL(dwh_kernel, dim3((ba.D * kHidden + 255) / 256, (N + kDwhSlice - 1) / kDwhSlice, 1 + ba.n_heads),
                                dim3(256), 0, st, ba, t->d_acts, t->d_dpre, t->d_grad, kDwhSlice);
-            return smh::launch_status("dwh_kernel");
+            rc = smh::launch_status("dwh_kernel");
+            return rc ? rc : det_finalize(t, st);
         }
         hipLaunchKernelGGL(dwh_mfma_kernel, dim3((ba.D / 16 + 3) / 4, 1 + ba.n_heads, kDwhSplit), dim3(256), 0, st, ba, t->d_acts,
                            t->d_dpre, t->d_grad);
-        return smh::launch_status("dwh_mfma_kernel");
+        rc = smh::launch_status("dwh_mfma_kernel");
+        return rc ? rc : det_finalize(t, st);
     }
     const int RP = kBG * ba.T;
     size_t lds = sizeof(float) * ((size_t)4 * RP * kBS + 2 * (3 * C * C + C * C) + C + 3 * RP + kBG * kPS);
@@ -1379,7 +1438,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tcn_backward_kernel, dim3((N + kBG - 1) / kBG), dim3(kBThreads), lds, st, ba, d_x, m->d_flat,
                        t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad);
-    return smh::launch_status("tcn_backward_kernel");
+    rc = smh::launch_status("tcn_backward_kernel");
+    return rc ? rc : det_finalize(t, st);
 }
 
 extern "C" size_t smh_trainer_bucket_floats(const smh_trainer *t) { return t ? t->m->n_params + kMaxHeads * 32 : 0; }

@@ -123,6 +123,9 @@ class TrainingMixin:
                                   clipnorm=1, momentum=0.9)
         self._rng = torch.Generator(device="cuda")
         self._rng.manual_seed(1234 + int(os.environ.get("RANK", "0")))  # data parallel: every rank draws its own masks
+        # bit-reproducible weight gradients (include/smh.h: smh_trainer_set_deterministic); SMH_DETERMINISTIC=1 turns it on for
+        # every model of the process, `model.deterministic_gradients = True` for one
+        self._deterministic = os.environ.get("SMH_DETERMINISTIC", "0") == "1"
 
     def learning_rate(self, step=None):
         """Learning rate of optimiser step `step` (default: the next one), e.g. ExponentialDecay(0.002, 3*TR_STEPS, 0.1)."""
@@ -200,7 +203,23 @@ class TrainingMixin:
         return self._trainer
 
     def _on_new_trainer(self):
-        pass
+        self._apply_deterministic()
+
+    def _apply_deterministic(self):
+        if self._trainer is not None and hasattr(self.lib, "smh_trainer_set_deterministic") and self._TRAINER_API[0] == "smh_trainer_create":
+            _lib.check(self.lib.smh_trainer_set_deterministic(self._trainer, 1 if self._deterministic else 0, _cur_stream()),
+                       "smh_trainer_set_deterministic")
+
+    @property
+    def deterministic_gradients(self):
+        """Weight gradients summed in 64-bit fixed point (integer atomics) instead of float atomics: bit-identical from run to
+        run.  The Conv2D baselines' trainer sums in ordered partials and is deterministic as it stands."""
+        return self._deterministic
+
+    @deterministic_gradients.setter
+    def deterministic_gradients(self, on):
+        self._deterministic = bool(on)
+        self._apply_deterministic()
 
     def _bucket_tensor(self):
         """torch view of the trainer's data-parallel bucket [flat gradient | BatchNorm batch statistics]."""

@@ -402,13 +402,13 @@ def test_growing_the_cnn_trainer_keeps_adam_moments_and_step():
         m.train_on_batch(x, y, drop=None, drop_heads=None)
         assert m._trainer_cap == 60 and m.iterations == 3
         res.append(m.get_weights_dict())
+    # The Conv2D trainer sums in ordered partials whose split depends on the BATCH, never on the trainer's capacity, and uses no
+    # float atomics: the grown trainer and the pre-sized one must agree bit for bit, in every tensor -- the Dense(16) biases in
+    # front of BatchNorm included (analytically zero gradients whose rounding noise Adam turns into +-lr steps: the first thing
+    # to move if any reduction order depended on the capacity).  Round 2 held this to 3e-2 with those biases skipped; measured in
+    # round 3 (tests/diag/cnn_grow_probe.py, three repetitions): identical after every step.
     for k in res[0]:
-        delta = np.abs(res[1][k] - w[k]).max()
-        # the two trainers split their reductions differently (partial-sum buffers are sized by the capacity): the gradients
-        # differ in the last bits and Adam's first steps are sign descent, so allow 3 % of the distance travelled
-        if k.endswith("/dense/bias"):
-            continue  # a bias in front of BatchNorm: analytically zero gradient, Adam turns its rounding noise into +-lr steps
-        assert np.abs(res[0][k] - res[1][k]).max() <= 3e-2 * delta + 1e-6, k
+        assert np.array_equal(res[0][k], res[1][k]), k
     # a trainer that forgot its state restarts the bias correction at step 1: the third update would be ~lr per weight,
     # visibly different
     m, w = _model(30, 68, seed=13)

@@ -171,7 +171,7 @@ def test_build_fit_save_reload_filewise_test_and_score(tmp_path):
     print("confusion matrix\n", ConfMat, "\nprecision", precision, "recall", recall, "fscore", fscore, "accuracy", acc)
     assert ConfMat.shape == (3, 3) and ConfMat.sum() == len(GroundTruth) >= 12
     # <= 1200 SGD steps, 63 training files per class (with 10 the network memorises its files: training accuracy 1.0, unseen
-    # files at chance -- measured, tools/diag/e2e_probe.py): every class above the 1/3 of chance on file-wise patches of UNSEEN files
+    # files at chance -- measured, tests/diag/e2e_probe.py): every class above the 1/3 of chance on file-wise patches of UNSEEN files
     assert acc > 0.5 and np.all(recall > 0.34)
     # the same predictions from the model that was trained in this process (the reload changed nothing)
     x0, _ = test_file_wise_generator(PARAMS, PARAMS['folder'] + '/speech/' + PARAMS['test_files']['speech'][0], '', None)

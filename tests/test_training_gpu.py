@@ -268,6 +268,47 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
         assert np.abs(bn[hi * 32 + 16:hi * 32 + 32] - var).max() <= 1e-4 * max(1.0, np.abs(var).max())
 
 
+@pytest.mark.parametrize("ncls,N", [(3, 510), (5, 510), (3, 600)])   # 600: past the heads kernel's LDS tile (its other path)
+def test_deterministic_gradients_are_bit_reproducible(ncls, N):
+    """`model.deterministic_gradients = True` (smh_trainer_set_deterministic): the weight-gradient contributions of the 510
+    workgroups are summed on a 2^-36 fixed-point grid with integer atomics instead of float atomics, so the sum does not depend
+    on arrival order -- three runs of the config-4 step give `torch.equal` gradients in EVERY tensor, and the same after the
+    mode is switched off and on again.  Against the default (float-atomic) gradient the values agree to float32 summation noise."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=21)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls)
+    m.set_weights_dict(w)
+    dt, dh = torch.from_numpy(drop_tcn).cuda(), torch.from_numpy(drop_heads).cuda()
+
+    def grad():
+        m.train_on_batch(x, y, drop_tcn=dt, drop_heads=dh, apply=False)
+        torch.cuda.synchronize()
+        return m._bucket_tensor().clone()   # gradient AND the BatchNorm batch statistics behind it
+    free = [grad() for _ in range(2)]
+    assert m.deterministic_gradients is False
+    m.deterministic_gradients = True
+    det = [grad() for _ in range(3)]
+    assert torch.equal(det[0], det[1]) and torch.equal(det[0], det[2])
+    m.deterministic_gradients = False
+    grad()
+    m.deterministic_gradients = True
+    assert torch.equal(grad(), det[0])
+    # same gradient as the default mode up to the float atomics' own summation noise
+    n = m.count_params()
+    scale = float(free[0][:n].abs().max())
+    assert float((det[0][:n] - free[0][:n]).abs().max()) <= 2e-6 * scale
+    # and two steps with the optimiser in the loop end in identical weights
+    ends = []
+    for _ in range(2):
+        mm = B3MTL(n_feat=240, patch_size=68, n_classes=ncls, TR_STEPS=10)
+        mm.set_weights_dict(w)
+        mm.deterministic_gradients = True
+        for _ in range(2):
+            mm.train_on_batch(x, y, drop_tcn=dt, drop_heads=dh)
+        ends.append(mm.get_weights())
+    assert all(np.array_equal(a, b) for a, b in zip(*ends))
+
+
 def test_growing_the_trainer_keeps_the_optimiser_state():
     """A batch larger than the trainer's capacity re-creates the native trainer: momentum must survive.  Step at N = 48, then
     at N = 96 (capacity 64 -> 96) against a model whose trainer had room for 96 from the start."""

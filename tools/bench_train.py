@@ -31,6 +31,8 @@ def main():
                     "k, as the reference's generator workers prepare the next batch while Keras trains on the current one -- "
                     "measured 0.825 -> 0.785 ms per 510-clip step; at 48 clips the step is launch-bound and the second stream costs 2 %)")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream form at any batch size")
+    ap.add_argument("--deterministic", action="store_true", help="bit-reproducible weight gradients (fixed-point integer atomics, "
+                    "smh_trainer_set_deterministic) instead of float atomics: states what determinism costs per step")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal (SMH_DIST_BACKEND=gloo on a CPU box): no compute")
     args = ap.parse_args()
     from sm_hpss_mtl_amd.launch import init_ranks, spawn_ranks_if_needed, timed_region
@@ -61,6 +63,7 @@ def main():
     shift = args.shift or (24 if W == 249 else W)
     fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
     model = B3MTL(n_feat=240, patch_size=W, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
+    model.deterministic_gradients = bool(args.deterministic)
     audio = torch.from_numpy(synth_clips(B, seed=2000 + rank)).cuda()  # B distinct clips per rank
     smr = np.array([(-5, 0, 5, 10, 15, 20)[i % 6] for i in range(bs)], np.float64)
     lab = make_labels_3class(bs, smr) if args.classes == 3 else make_labels_5class(bs, smr, smr[::-1].copy())
@@ -133,6 +136,7 @@ def main():
             "unit": "clips/s", "n_gpus": world, "ranks_reporting": ran, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "dtype": "f32",
             "data": "synthetic", "front_end_overlapped_with_previous_step": not serial,
+            "deterministic_gradients": bool(args.deterministic),
             "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=%d patches (%d per clip) -> B3_MTL(%d-class) "
                                             "train step, SGD(momentum 0.9, clipnorm 1)" % (B, W, nP, args.classes),
                                             "gradient_allreduce_bytes": 4 * model.count_params() if world > 1 else 0},
