@@ -91,6 +91,9 @@ int smh_median_freq_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int 
  * tiny axes outside the fused kernel table); pass that value on to smh_features_ex_f32.              */
 int smh_hpss_median_ex_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_harm, int l_perc,
                            float *d_harm, float *d_perc, int harm_layout, void *stream);
+/* the harmonic median alone (= smh_median_time_f32) in any of those layouts; returns the layout written */
+int smh_median_time_ex_f32(const smh_ctx *ctx, const float *d_S, int B, int K, int T, int l_harm, float *d_harm,
+                           int harm_layout, void *stream);
 
 /* ---- a3: H = S*softmask(harm,perc), P = S*softmask(perc,harm); power=2, split_zeros=True ---- */
 int smh_softmask_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc, size_t n,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "smh_hpss_median_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "smh_hpss_median_ex_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _i, _vp]),
     "smh_median_time_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
+    "smh_median_time_ex_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _i, _vp]),
     "smh_median_freq_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "smh_softmask_f32": (_i, [_vp, _fp, _fp, _fp, _sz, _fp, _fp, _vp]),
     "smh_mel_f32": (_i, [_vp, _fp, _i, _i, _fp, _vp]),

@@ -813,7 +813,8 @@ __global__ void fill_int_kernel(int *p, int n, int v) {
 // ---------------------------------------------------------------------------------------------------
 // TRACE: tools/trace_features.py only.  The stamps cost registers (93 instead of 78, i.e. the third workgroup per CU); the
 // TRACE build is therefore held to 80 VGPRs and spills ten of them: its timeline is indicative, not the plain build's.
-template <int NP, bool TRACE = false>
+// PROBE: tools/perc_in_walk_bound.py only (SMH_FEAT_PROBE_PERC): a separate instantiation, the plain kernel's registers stay as they are
+template <int NP, bool TRACE = false, bool PROBE = false>
 __global__ void __launch_bounds__(512, (TRACE ? 6 : 1))
 features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int B, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
@@ -827,6 +828,11 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     const int half = rr >> 3, b = grp * 8 + (rr & 7);
     if (b >= B) return;
     const bool w0_lds = !(stop_after & 16);  // bit 4 of the probe argument: layer-0 weights from L2 instead of an LDS copy
+    // bits 8..15 (timing probe SMH_FEAT_PROBE_PERC = n, outputs invalid): what "the percussive median inside this walk" would
+    // cost -- perc is NOT read (S stands in for it), every bin step issues 2 n selection instructions (n per frame of the lane's
+    // pair: the block-split scheme needs 17.6 per output at window 17) and every segment walks l_perc - 1 = 16 more bins of S
+    // in front (the window's warm-up).  tools/perc_in_walk_bound.py.
+    const int probe_n = PROBE ? (stop_after >> 8) & 255 : 0;
     stop_after &= 15;
     const int ld = T | 1, R2 = 2 * rows;
     float *s_mean = img + (size_t)rows * ld;  // mean hi [rows], 1/scale [rows], mean lo [rows]
@@ -878,8 +884,25 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             ++mcur;
         };
         // "own" = the median this half's mask favours (harm for H, perc for P): out = S own^2 / (own^2 + other^2)
-        const float *Sb = S + cb + t0, *Pb = perc + cb + t0;
+        const float *Sb = S + cb + t0, *Pb = ((PROBE && probe_n) ? S : perc) + cb + t0;
         const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
+        float pd0 = 0.f, pd1 = 1.f;  // (probe) the dummy window the selection instructions work on
+        auto probe_select = [&](f32x2 v) {
+            for (int i = 0; i < probe_n; i += 6) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(pd0) : "v"(v.x), "v"(pd1));
+                    asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(pd1) : "v"(v.y), "v"(pd0));
+                }
+            }
+        };
+        if (PROBE && probe_n) {  // the window's warm-up: 16 more bins of S in front of the segment (reflected at the clip's edge)
+            f32x2 hv16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) hv16[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)max(kbeg - 16 + u, 0) * T);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) probe_select(hv16[u]);
+        }
         for (int k0 = kbeg; k0 < kend; k0 += kHalfBatch) {
             f32x2 sv[kHalfBatch], pv[kHalfBatch], hv[kHalfBatch];
             float4 wq[kHalfBatch];
@@ -898,6 +921,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             for (int u = 0; u < kHalfBatch; ++u) {
                 if (k0 + u >= kend) break;
                 for (int i = 0; i < ne[u]; ++i) emit_first();
+                if (PROBE && probe_n) probe_select(sv[u]);
                 const f32x2 own = half ? pv[u] : hv[u], oth = half ? hv[u] : pv[u];
                 const f32x2 o2 = own * own;
                 const f32x2 den = o2 + oth * oth;
@@ -1159,7 +1183,8 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
     fp.plan = c->d_feat_plan;
     fp.trace = g_feat_trace;
     const char *stop_ev = smh::probe_env("SMH_FEAT_STOP");  // timing probe: the kernel returns early
-    const int stop = stop_ev ? atoi(stop_ev) : 0;
+    int stop = stop_ev ? atoi(stop_ev) & 15 : 0;
+    if (const char *pe = smh::probe_env("SMH_FEAT_PROBE_PERC")) stop |= (std::max(0, std::min(atoi(pe), 255)) << 8);  // see the kernel
     if (pair) {
         // half the LDS per workgroup: two share a CU.  The 8 waves take the 8-segment plan, one segment each: every segment
         // boundary costs a re-read of the bins its filters straddle (8 segments: 280 bin reads for 201 bins; 16 segments,
@@ -1171,7 +1196,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         // needs 49 KB and THREE share a CU (77 VGPRs: 6 waves per SIMD) -- 127-130 -> 113-115 us; SMH_FEAT_W0LDS=1: the copy
         const bool w0_l2 = getenv("SMH_FEAT_W0LDS") == nullptr;
         if (x0p && !w0_l2) ldh += sizeof(float) * rows * 32;
-        const int probe = (stop & 15) | (w0_l2 ? 16 : 0);
+        const int probe = (stop & ~16) | (w0_l2 ? 16 : 0);
         const unsigned grid = 16u * (unsigned)((B + 7) / 8);
         if (getenv("SMH_FEAT_OCC")) {  // tools only: what the runtime says about residency
             int nb = -1;
@@ -1180,14 +1205,16 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
             (void)hipFuncGetAttributes(&fa, (const void *)features_half_kernel<2, false>);
             fprintf(stderr, "features_half_kernel<2>: dynamic LDS %zu B, regs %d, occupancy %d workgroups per CU\n", ldh, fa.numRegs, nb);
         }
-#define SMH_LAUNCH_HALF(NPV, TR)                                                                                          \
+#define SMH_LAUNCH_HALF(NPV, TR, ...)                                                                                     \
     do {                                                                                                                \
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<NPV, TR>,                                  \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<NPV, TR, ##__VA_ARGS__>,                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));                      \
-        hipLaunchKernelGGL((features_half_kernel<NPV, TR>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S,  \
+        hipLaunchKernelGGL((features_half_kernel<NPV, TR, ##__VA_ARGS__>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, \
                            harmb, perc, B, K, T, rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);     \
     } while (0)
-        if (fp.trace) {
+        if (probe >> 8) {  // SMH_FEAT_PROBE_PERC: the instantiation with the probe compiled in (outputs invalid)
+            SMH_LAUNCH_HALF(2, false, true);
+        } else if (fp.trace) {
             if (fp.pend <= 2) SMH_LAUNCH_HALF(2, true);
             else SMH_LAUNCH_HALF(4, true);
         } else {

@@ -269,6 +269,23 @@ extern "C" int smh_median_time_f32(const smh_ctx *, const float *d_S, int B, int
     return launch(d_S, B, K, T, l_harm, 0, d_harm, nullptr, st);
 }
 
+// the harmonic median alone in any of the three layouts of smh_hpss_median_ex_f32 (returns the layout written)
+extern "C" int smh_median_time_ex_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_harm, float *d_harm,
+                                      int harm_layout, void *stream) {
+    int rc = check_args(d_S, B, K, T, l_harm, "smh_median_time_ex_f32");
+    if (rc) return rc;
+    SMH_REQUIRE(harm_layout >= 0 && harm_layout <= 2, "smh_median_time_ex_f32: harm_layout must be 0, 1 or 2");
+    SMH_REQUIRE(d_harm || B == 0, "smh_median_time_ex_f32: null output");
+    if (B == 0) return harm_layout;
+    if (l_harm == 1 || !fast_ok(T, l_harm) || harm_layout == 0) {
+        rc = smh_median_time_f32(nullptr, d_S, B, K, T, l_harm, d_harm, stream);
+        return rc ? rc : 0;
+    }
+    int written = harm_layout;
+    rc = launch(d_S, B, K, T, l_harm, 0, d_harm, nullptr, (hipStream_t)stream, harm_layout, &written);
+    return rc ? rc : written;
+}
+
 extern "C" int smh_median_freq_f32(const smh_ctx *, const float *d_S, int B, int K, int T, int l_perc, float *d_perc,
                                    void *stream) {
     int rc = check_args(d_S, B, K, T, l_perc, "smh_median_freq_f32");
