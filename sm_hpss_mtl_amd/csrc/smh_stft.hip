@@ -226,6 +226,101 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
 constexpr int kF400 = 32;    // upper bound of frames per workgroup: phase 2 has 8 items per frame
 constexpr int kMP400 = 201;  // float2 stride of one frame in LDS
 
+// Complex arithmetic on (re, im) register PAIRS for stft400_kernel.  hipcc packs float2 math into v_pk_* instructions but
+// builds every swapped / negated operand ((-i) b, conj b, the cross terms of a complex product) with v_mov / v_pk_mov into a new
+// pair first: 333 of the kernel's 1000 VALU instructions were such moves (round 2), and a VALU instruction costs the SIMD four
+// cycles whatever it does.  The VOP3P encoding selects and negates the halves of each source itself (op_sel, op_sel_hi,
+// neg_lo, neg_hi), so these patterns are single instructions -- spelled out here because the compiler does not form them:
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 sub_i(v2 a, v2 b) {  // a - i b = (a.x + b.y, a.y - b.x)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2 add_i(v2 a, v2 b) {  // a + i b = (a.x - b.y, a.y + b.x)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2 add_conj(v2 a, v2 b) {  // a + conj(b) = (a.x + b.x, a.y - b.y)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2 sub_conj(v2 a, v2 b) {  // a - conj(b) = (a.x - b.x, a.y + b.y)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2 cmulp(v2 a, v2 w) {  // a w: (a.x w.x, a.x w.y) then (- a.y w.y, + a.y w.x) on top
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// the same with a compile-time twiddle kept in a scalar register pair (one constant-bus operand per instruction)
+__device__ __forceinline__ v2 cmulp_s(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+
+__device__ __forceinline__ void pk_dft4(v2 &a, v2 &b, v2 &c, v2 &d) {
+    const v2 s0 = a + c, d0 = a - c, s1 = b + d, bd = b - d;
+    a = s0 + s1;
+    b = sub_i(d0, bd);  // d0 + (-i)(b - d)
+    c = s0 - s1;
+    d = add_i(d0, bd);
+}
+__device__ __forceinline__ void pk_dft8(v2 *v) {  // 8 = 2 x 4: even / odd 4-point DFTs, odd outputs twisted by w8^k
+    v2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    pk_dft4(e0, e1, e2, e3);
+    pk_dft4(o0, o1, o2, o3);
+    const float h = 0.70710678118654752440f;
+    const v2 u1 = sub_i(o1, o1);  // o1 (1 - i)
+    const v2 u3 = add_i(o3, o3);  // o3 (1 + i): w8^3 o3 = -h u3
+    v[0] = e0 + o0, v[4] = e0 - o0;
+    v[1] = e1 + h * u1, v[5] = e1 - h * u1;
+    v[2] = sub_i(e2, o2), v[6] = add_i(e2, o2);  // w8^2 = -i
+    v[3] = e3 - h * u3, v[7] = e3 + h * u3;
+}
+__device__ __forceinline__ void pk_dft5(v2 *v) {  // Winograd-style 5-point DFT
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const v2 t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+    const v2 a1 = v[0] + c1 * t1 + c2 * t2, a2 = v[0] + c2 * t1 + c1 * t2;
+    const v2 b1 = s1 * t3 + s2 * t4, b2 = s2 * t3 - s1 * t4;
+    v[0] = v[0] + t1 + t2;
+    v[1] = sub_i(a1, b1), v[4] = add_i(a1, b1);
+    v[2] = sub_i(a2, b2), v[3] = add_i(a2, b2);
+}
+__device__ __forceinline__ void pk_dft25(v2 *x) {
+    // x[5a + b] -> X[c + 5d]:  inner DFT over a (output c), twiddle W_25^(b c), outer DFT over b (output d)
+    v2 t[5][5];  // t[c][b]
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        v2 u[5] = {x[b], x[5 + b], x[10 + b], x[15 + b], x[20 + b]};
+        pk_dft5(u);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            if (b * c == 0) {
+                t[c][b] = u[c];
+            } else {
+                const double ang = -6.283185307179586476925 * (double)(b * c) / 25.0;
+                t[c][b] = cmulp_s(u[c], v2{(float)__builtin_cos(ang), (float)__builtin_sin(ang)});
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        pk_dft5(t[c]);
+#pragma unroll
+        for (int d = 0; d < 5; ++d) x[c + 5 * d] = t[c][d];
+    }
+}
+
 __device__ __forceinline__ void dft25(float2 *x) {
     // x[5a + b] -> X[c + 5d]:  inner DFT over a (output c), twiddle W_25^(b c), outer DFT over b (output d)
     float2 t[5][5];  // t[c][b]
@@ -258,10 +353,10 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
     constexpr int M = 200, K = 201;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    float2 *tw = lds;             // M twiddles
-    float2 *tw2 = tw + M;         // M + 1 untangle twiddles
-    float2 *win2 = tw2 + (M + 2); // window as (w[2m], w[2m+1])
-    float2 *Z = win2 + M;         // F frames of kMP400
+    v2 *tw = reinterpret_cast<v2 *>(lds);  // M twiddles
+    v2 *tw2 = tw + M;         // M + 1 untangle twiddles
+    v2 *win2 = tw2 + (M + 2); // window as (w[2m], w[2m+1])
+    v2 *Z = win2 + M;         // F frames of kMP400
     const int b = blockIdx.y, t0 = blockIdx.x * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
     const int nthr = blockDim.x;
@@ -272,14 +367,14 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     // one for the tables and one per round (a round's loads used to be issued when the previous round's butterflies were done).
     constexpr int kRounds1 = 3;
     const bool ahead = 25 * nf <= kRounds1 * nthr;
-    float2 au[kRounds1][8];
+    v2 au[kRounds1][8];
     int fr_[kRounds1], n2_[kRounds1];
     if (ahead) {
         int f = tid / 25, n2 = tid - (tid / 25) * 25;
 #pragma unroll
         for (int r = 0; r < kRounds1; ++r) {
             fr_[r] = f, n2_[r] = n2;
-            const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(min(f, nf - 1) * hop));
+            const v2 *fr = reinterpret_cast<const v2 *>(clip + (unsigned)(min(f, nf - 1) * hop));
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) au[r][n1] = fr[25 * n1 + n2];
             n2 += dr1;
@@ -292,24 +387,21 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     // entries (indexed n2 * k1 the reads were strided by k1: up to 4 lanes per bank)
     for (int i = tid; i < M; i += nthr) {
         const int k1 = i / 25;
-        tw[i] = twM[(i - 25 * k1) * k1];
-        win2[i] = reinterpret_cast<const float2 *>(window)[i];
+        tw[i] = reinterpret_cast<const v2 *>(twM)[(i - 25 * k1) * k1];
+        win2[i] = reinterpret_cast<const v2 *>(window)[i];
     }
-    for (int i = tid; i <= M; i += nthr) tw2[i] = tw2M[i];
+    for (int i = tid; i <= M; i += nthr) tw2[i] = reinterpret_cast<const v2 *>(tw2M)[i];
     __syncthreads();
 
     // phase 1
-    auto butterfly1 = [&](float2 (&v)[8], int f, int n2) {
+    auto butterfly1 = [&](v2 (&v)[8], int f, int n2) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const float2 w = win2[25 * n1 + n2];
-            v[n1] = make_float2(v[n1].x * w.x, v[n1].y * w.y);
-        }
-        dft<8>(v);
-        float2 *zf = Z + f * kMP400 + n2;
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = v[n1] * win2[25 * n1 + n2];
+        pk_dft8(v);
+        v2 *zf = Z + f * kMP400 + n2;
         zf[0] = v[0];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmul(v[k1], tw[25 * k1 + n2]);
+        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmulp(v[k1], tw[25 * k1 + n2]);
     };
     if (ahead) {
 #pragma unroll
@@ -317,8 +409,8 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
             if (fr_[r] < nf) butterfly1(au[r], fr_[r], n2_[r]);
     } else {
         for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf;) {
-            const float2 *fr = reinterpret_cast<const float2 *>(clip + (unsigned)(f * hop));
-            float2 v[8];
+            const v2 *fr = reinterpret_cast<const v2 *>(clip + (unsigned)(f * hop));
+            v2 v[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) v[n1] = fr[25 * n1 + n2];
             butterfly1(v, f, n2);
@@ -330,23 +422,25 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     }
     __syncthreads();
     // phase 2: read, barrier, compute, write in place (natural order); 8 * F <= blockDim.x items.
-    // Banks: a half-wave holds 4 frames x 8 k1, float2 offsets 201 f + 25 k1 + n2.  In float2 units mod 32 the k1 terms are
-    // A = {0,25,18,11,4,29,22,15}; frames add 9 f.  A + 9 misses A, A + 18 meets it in 6 of 8 (frames f, f + 2: 2-way).  Four
-    // disjoint translates of A need pairwise differences outside A - A, e.g. {0,8,16,24} = a frame stride of 200 -- which puts
-    // phase 3's 20 frame-fastest lanes on 4 banks.  The odd stride keeps phase 3 (the longer phase) clean.
+    // Banks: the 25 reads of an item compile to ds_read2_b64, which LDS serves in groups of 16 consecutive lanes over 32
+    // dword banks.  Items are laid out FRAMES FASTEST (item = k1 * nf + f): a 16-lane group then holds 16 frames of one k1, float2
+    // offsets 201 f + 25 k1 + n2, and 201 = 9 (mod 16) is odd -- 16 distinct bank pairs.  (Round 2 had k1 fastest: 2 frames x 8 k1
+    // per group, offsets 9 f + 9 k1 (mod 16), the two frames' sets meeting in 6 of 8 -- two-way conflicts on every access, and no
+    // frame stride serves that layout and phase 3's frame-fastest lanes at once: 8 (mod 16) here against odd there.)  Only the
+    // groups that straddle two k1 (nf is not a multiple of 16) still meet, in at most 3 of their 16 lanes.
     {
-        const int f = tid >> 3, k1 = tid & 7;
-        const bool live = f < nf;
-        float2 x[25];
+        const int k1 = tid / nf, f = tid - k1 * nf;
+        const bool live = k1 < 8;
+        v2 x[25];
         if (live) {
-            const float2 *zf = Z + f * kMP400 + k1 * 25;
+            const v2 *zf = Z + f * kMP400 + k1 * 25;
 #pragma unroll
             for (int n2 = 0; n2 < 25; ++n2) x[n2] = zf[n2];
         }
         __syncthreads();
         if (live) {
-            dft25(x);
-            float2 *zo = Z + f * kMP400 + k1;
+            pk_dft25(x);
+            v2 *zo = Z + f * kMP400 + k1;
 #pragma unroll
             for (int k2 = 0; k2 < 25; ++k2) zo[8 * k2] = x[k2];
         }
@@ -359,21 +453,20 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     const int dq = nthr / nf, dr = nthr - dq * nf;
     int k = tid / nf, f = tid - k * nf;
     for (; k <= M / 2; ) {
-        const float2 *zf = Z + f * kMP400;
-        const float2 A = zf[k], Bz = zf[k == 0 ? 0 : M - k];
+        const v2 *zf = Z + f * kMP400;
+        const v2 A = zf[k], Bz = zf[k == 0 ? 0 : M - k];
         // X[k] = (e - i g) / 2 and X[M-k] = conj(e + i g) / 2 with e = A + conj(B), g = tw2[k] (A - conj(B)):
-        // one twiddle product serves both bins of the pair
-        const float2 zc = make_float2(Bz.x, -Bz.y);
-        const float2 e = cadd(A, zc), d = csub(A, zc);
-        const float2 g = cmul(tw2[k], d);
+        // one twiddle product serves both bins of the pair; the halving is exact, so it is taken on the magnitude
+        const v2 e = add_conj(A, Bz), d = sub_conj(A, Bz);
+        const v2 g = cmulp(d, tw2[k]);
         {
-            const float re = 0.5f * (e.x + g.y), im = 0.5f * (e.y - g.x);
-            const float v = mag(re, im);
+            const v2 x = sub_i(e, g);  // (e.x + g.y, e.y - g.x)
+            const float v = 0.5f * mag(x.x, x.y);
             if (!probe || v == -1.f) Sb[(unsigned)(k * T + f)] = v;
         }
         if (k != M / 2) {
-            const float re = 0.5f * (e.x - g.y), im = 0.5f * (e.y + g.x);
-            const float v = mag(re, im);
+            const v2 x = add_i(e, g);  // (e.x - g.y, e.y + g.x)
+            const float v = 0.5f * mag(x.x, x.y);
             if (!probe || v == -1.f) Sb[(unsigned)((M - k) * T + f)] = v;
         }
         f += dr;
