@@ -886,6 +886,10 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         // "own" = the median this half's mask favours (harm for H, perc for P): out = S own^2 / (own^2 + other^2)
         const float *Sb = S + cb + t0, *Pb = ((PROBE && probe_n) ? S : perc) + cb + t0;
         const float *Hb = hclip + (size_t)(t0 >> 4) * K * 16 + (t0 & 15);
+        // own / other as (base, bin stride) pairs chosen once per workgroup: the loads land in the registers the mask reads
+        // (selecting own / other per bin cost four v_cndmask per bin step, a quarter of the walk's VALU instructions)
+        const float *OwnB = half ? Pb : Hb, *OthB = half ? Hb : Pb;
+        const int own_st = half ? T : 16, oth_st = half ? 16 : T;
         float pd0 = 0.f, pd1 = 1.f;  // (probe) the dummy window the selection instructions work on
         auto probe_select = [&](f32x2 v) {
             for (int i = 0; i < probe_n; i += 6) {
@@ -904,15 +908,15 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             for (int u = 0; u < 16; ++u) probe_select(hv16[u]);
         }
         for (int k0 = kbeg; k0 < kend; k0 += kHalfBatch) {
-            f32x2 sv[kHalfBatch], pv[kHalfBatch], hv[kHalfBatch];
+            f32x2 sv[kHalfBatch], ov[kHalfBatch], tv[kHalfBatch];  // S, own median, other median
             float4 wq[kHalfBatch];
             int ne[kHalfBatch];
 #pragma unroll
             for (int u = 0; u < kHalfBatch; ++u) {
                 const int kk = min(k0 + u, K - 1);
                 sv[u] = *reinterpret_cast<const f32x2 *>(Sb + (size_t)kk * T);
-                pv[u] = *reinterpret_cast<const f32x2 *>(Pb + (size_t)kk * T);
-                hv[u] = *reinterpret_cast<const f32x2 *>(Hb + (size_t)kk * 16);
+                ov[u] = *reinterpret_cast<const f32x2 *>(OwnB + (size_t)kk * own_st);
+                tv[u] = *reinterpret_cast<const f32x2 *>(OthB + (size_t)kk * oth_st);
                 const int pi = min(k0 + u, kend - 1) - kbeg;
                 wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
                 ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
@@ -922,15 +926,15 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
                 if (k0 + u >= kend) break;
                 for (int i = 0; i < ne[u]; ++i) emit_first();
                 if (PROBE && probe_n) probe_select(sv[u]);
-                const f32x2 own = half ? pv[u] : hv[u], oth = half ? hv[u] : pv[u];
+                const f32x2 own = ov[u], oth = tv[u];
                 const f32x2 o2 = own * own;
                 const f32x2 den = o2 + oth * oth;
                 f32x2 X;
                 constexpr float kDenMin = 7.8886091e-31f;  // 2^-100
                 if (__builtin_expect(__any(den.x < kDenMin || den.y < kDenMin), 0)) {
-                    float Hx, Px, Hy, Py;
-                    hpss_masks_fast(sv[u].x, hv[u].x, pv[u].x, Hx, Px);
-                    hpss_masks_fast(sv[u].y, hv[u].y, pv[u].y, Hy, Py);
+                    float Hx, Px, Hy, Py;  // (rare: digital silence) the normalised form, harmonic median first
+                    hpss_masks_fast(sv[u].x, half ? oth.x : own.x, half ? own.x : oth.x, Hx, Px);
+                    hpss_masks_fast(sv[u].y, half ? oth.y : own.y, half ? own.y : oth.y, Hy, Py);
                     X = half ? f32x2{Px, Py} : f32x2{Hx, Hy};
                 } else {
                     X = o2 * (sv[u] * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
