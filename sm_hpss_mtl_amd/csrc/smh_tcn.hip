@@ -961,10 +961,12 @@ static void pack_host(const smh_model *m, const float *h, std::vector<float> &W0
         php += cnt;
         p += cnt;
     }
-    // Wh[k][ld], ld = 64 * ceil(NH / 64): row k = the NH outputs of input k (then zeros), read one row per wave and k
+    // Wh[k / 4][ld][k % 4], ld = 64 * ceil(NH / 64): four consecutive inputs k (= four channels of one frame) of output o lie
+    // together, so a lane fetches them with ONE 16-byte load (a wave: 1 KiB per instruction) where the [k][ld] layout took four
+    // dword loads -- the Dense phase streams 557 KB per workgroup from L2 and was bound by the number of its load instructions
     const int ld = 64 * ((NH + 63) / 64);
     for (int k = 0; k < D; ++k)
-        for (int o = 0; o < NH; ++o) WhA[(size_t)k * ld + o] = Wh[(size_t)k * NH + o];
+        for (int o = 0; o < NH; ++o) WhA[(size_t)(k / 4) * ld * 4 + (size_t)o * 4 + (k % 4)] = Wh[(size_t)k * NH + o];
     std::memcpy(&WhA[(size_t)D * ld], bhv.data(), bhv.size() * sizeof(float));
 }
 

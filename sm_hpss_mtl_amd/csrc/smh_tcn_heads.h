@@ -43,14 +43,16 @@ __device__ __forceinline__ void dense_and_heads(const TcnArgs &a, const float *x
 #pragma unroll
                     for (int p = 0; p < kOPL; ++p) acc[g][p] = 0.f;
                 for (int t = t_lo; t < t_hi; ++t) {
-                    const float *wrow = WhA + (size_t)t * C * ld + lane;
+                    // weights: [k / 4][ld][4] (pack_host): the four channels 4 h .. 4 h + 3 of frame t for this lane's output
+                    const f32x4 *wrow = reinterpret_cast<const f32x4 *>(WhA) + (size_t)t * (C / 4) * ld + lane;
 #pragma unroll 2
                     for (int c8 = 0; c8 < 4; ++c8) {
-                        float wv[8][kOPL];
+                        f32x4 wa[kOPL], wb[kOPL];
 #pragma unroll
-                        for (int c = 0; c < 8; ++c)
-#pragma unroll
-                            for (int p = 0; p < kOPL; ++p) wv[c][p] = wrow[(size_t)(8 * c8 + c) * ld + 64 * p];
+                        for (int p = 0; p < kOPL; ++p) {
+                            wa[p] = wrow[(size_t)(2 * c8) * ld + 64 * p];
+                            wb[p] = wrow[(size_t)(2 * c8 + 1) * ld + 64 * p];
+                        }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x4 xa = *reinterpret_cast<const f32x4 *>(xg[g] + (size_t)t * SX + 8 * c8);
@@ -58,9 +60,9 @@ __device__ __forceinline__ void dense_and_heads(const TcnArgs &a, const float *x
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                                for (int p = 0; p < kOPL; ++p) {
-                                    acc[g][p] = fmaf(xa[c], wv[c][p], acc[g][p]);
-                                    acc[g][p] = fmaf(xb[c], wv[4 + c][p], acc[g][p]);
+                                for (int p = 0; p < kOPL; ++p) {  // (the summation order of the [k][ld] layout: bit-identical results)
+                                    acc[g][p] = fmaf(xa[c], wa[p][c], acc[g][p]);
+                                    acc[g][p] = fmaf(xb[c], wb[p][c], acc[g][p]);
                                 }
                         }
                     }
