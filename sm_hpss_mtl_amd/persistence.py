@@ -308,12 +308,23 @@ class HeadModel:
             bce = float(np.mean(-(t * np.log(oc + eps) + (1 - t) * np.log(1 - oc + eps))))
             w = self.model.get_weights_dict()[self.name + "/dense/kernel"].astype(np.float64)
             return np.array([bce + 0.01 * float(np.sum(w * w)), float(np.mean((o > 0.5) == (t > 0.5)))])
+        # data parallel: row-weighted sums all-reduced, as in TrainingMixin.evaluate (the loss of the global batch on every rank)
+        from .training import _host_collective, process_group
+        dist = process_group()
         if y is not None:
-            return list(one(x, y))
-        if steps is None:
-            raise ValueError("evaluate(generator) needs steps=")
-        tot = sum(one(*next(x)) for _ in range(int(steps)))
-        return list(tot / max(int(steps), 1))
+            tot, cnt = one(x, y) * float(len(x)), float(len(x))
+        else:
+            if steps is None:
+                raise ValueError("evaluate(generator) needs steps=")
+            tot, cnt = np.zeros(2), 0.0
+            for _ in range(int(steps)):
+                bx, by = next(x)
+                rows = float(len(bx)) if dist is not None else 1.0
+                tot, cnt = tot + one(bx, by) * rows, cnt + rows
+        if dist is not None:
+            red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
+            tot, cnt = red[:-1], red[-1]
+        return list(tot / max(cnt, 1.0))
 
     # ---- weights: the sub-model's own tensors (trunk + this head), as a Keras sub-model would save them ----
     def _own(self, name):

@@ -429,6 +429,10 @@ class TrainingMixin:
                 if arrays:
                     sl = slice((s * bs) % len(xs), (s * bs) % len(xs) + bs)
                     bx, by = xs[sl], [np.asarray(a)[sl] for a in yl]
+                    if world > 1:  # data parallel: this rank's rows of the global batch (round-robin, like the generator)
+                        from .sharding import shard_indices
+                        mine = shard_indices(len(bx), rank, world)
+                        bx, by = bx[mine], [a[mine] for a in by]
                 else:
                     bx, by = next(x)
                 raw = self._train_step_raw(bx, by)

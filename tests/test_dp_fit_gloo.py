@@ -122,6 +122,35 @@ def test_two_ranks_stop_on_the_same_epoch_with_identical_weights(tmp_path):
     assert len(rows) == n0 and float(rows[2]["val_loss"]) == pytest.approx(want_val[2])
 
 
+def _array_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = Scripted(SCRIPTS[rank], rank)
+        seen = []
+        step = m._train_step_raw
+        m._train_step_raw = lambda bx, by: (seen.append(np.asarray(bx)[:, 0, 0].copy()), step(bx, by))[1]
+        x = np.arange(12, dtype=np.float32)[:, None, None] * np.ones((1, 68, 240), np.float32)
+        y = [np.zeros((12, 1)), np.zeros((12, 1)), np.zeros((12, 2)), np.zeros((12, 3))]
+        m.fit(x, y, batch_size=6, epochs=1, verbose=0)
+        q.put((rank, [a.tolist() for a in seen]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_array_batches_are_shared_out_between_the_ranks():
+    """fit(x, y, batch_size=) under two ranks: each global batch of 6 rows is split round-robin, 3 rows per rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_array_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=180) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert res[0] == [[0.0, 2.0, 4.0], [6.0, 8.0, 10.0]] and res[1] == [[1.0, 3.0, 5.0], [7.0, 9.0, 11.0]]
+
+
 # ---- the generator's ranks build one global batch and take their rows of it ------------------------------------------------
 from tests.test_generators import _files, _fv, _params, _patches  # noqa: E402  (the stand-in files / per-file callables)
 from sm_hpss_mtl_amd import generators as gen  # noqa: E402
