@@ -380,3 +380,64 @@ def test_b3mtl_forward_outputs_vs_torch_nn(ncls, W):
     for a, b in zip(outs, ref_outs):
         assert a.shape == tuple(b.shape)
         np.testing.assert_allclose(a, b.numpy(), atol=1e-6)
+
+
+# ---- transformers.audio_utils: an independent, librosa-compatible implementation of the mel filter bank, the dB conversion and
+# the spectrogram (the feature extraction behind Whisper etc., written to reproduce librosa's numbers) that IS installed here.
+def test_mel_basis_vs_transformers_audio_utils():
+    """`oracle.frontend.mel_basis(22050, 400, 120)` -- the restatement of librosa.filters.mel(sr=22050, n_fft=400, n_mels=120,
+    fmin=0, fmax=sr/2, htk=False, norm='slaney'), the bank the reference gets through its `sr` quirk -- against
+    transformers.audio_utils.mel_filter_bank(norm='slaney', mel_scale='slaney'): float32 rounding apart (2.4e-9 absolute), the
+    same 393 non-zero taps and the same single all-zero filter (both libraries warn about it, as librosa does)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = au.mel_filter_bank(201, 120, 0.0, 11025.0, 22050, norm="slaney", mel_scale="slaney").T   # (120, 201) float64
+    got = ofe.mel_basis(22050.0, 400, 120)
+    assert got.shape == ref.shape == (120, 201) and got.dtype == np.float32
+    assert np.max(np.abs(got - ref)) <= 5e-9
+    assert np.array_equal(got > 0, ref > 0) and int((got > 0).sum()) == 393
+    assert np.array_equal(np.flatnonzero(got.sum(1) == 0), np.flatnonzero(ref.sum(1) == 0)) and int((got.sum(1) == 0).sum()) == 1
+    # Jang's bank (librosa.filters.mel(16000, n_fft=512, n_mels=120), lib/proposed_architectures.py:681)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref2 = au.mel_filter_bank(257, 120, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+    assert np.max(np.abs(ofe.mel_basis(16000.0, 512, 120) - ref2)) <= 5e-9
+
+
+def test_power_to_db_vs_transformers_audio_utils():
+    """librosa.core.power_to_db(x, ref=1.0, amin=1e-10, top_db=80.0) as restated against transformers' power_to_db with the same
+    three constants: 1e-5 dB (float32 log10)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    rng = np.random.default_rng(0)
+    x = (np.abs(rng.standard_normal((120, 98))) * 3).astype(np.float32)
+    x[5, :7] = 0.0          # below amin
+    x[9, 3] = 1e-7          # below the top_db floor of this array
+    ref = au.power_to_db(x.astype(np.float64) ** 2, reference=1.0, min_value=1e-10, db_range=80.0)
+    got = ofe.power_to_db(x ** 2)
+    assert got.dtype == np.float32 and np.max(np.abs(got - ref)) <= 1e-4
+    assert abs(float(got.min()) - (float(got.max()) - 80.0)) <= 1e-4
+
+
+def test_stft_mel_db_chain_vs_transformers_spectrogram(clips4):
+    """|STFT| (center=False, periodic Hann 400 / hop 160) -> mel(22050 quirk) -> dB with top_db 80, i.e. the reference's
+    LogMel branch WITHOUT the HPSS masks (for which no second implementation exists offline), end to end against
+    transformers.audio_utils.spectrogram(power=1, mel_filters=, log_mel='dB', db_range=80): 2e-3 dB on every bin above the
+    floor (the two chains round |S| differently: complex64 here, float64 there)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fb = au.mel_filter_bank(201, 120, 0.0, 11025.0, 22050, norm="slaney", mel_scale="slaney")
+    win = au.window_function(400, "hann", periodic=True)
+    assert np.array_equal(win, ofe.hann_window(400, 400)) or np.max(np.abs(win - ofe.hann_window(400, 400))) < 1e-15
+    for y in clips4[:2]:
+        ref = au.spectrogram(y.astype(np.float64), win, frame_length=400, hop_length=160, fft_length=400, power=1.0, center=False,
+                             mel_filters=fb, mel_floor=1e-5, log_mel="dB", reference=1.0, min_value=1e-5, db_range=80.0,
+                             dtype=np.float64)
+        got = ofe.power_to_db(ofe.mel_project(ofe.stft_mag(y), 120) ** 2)
+        assert got.shape == ref.shape == (120, 98)
+        live = (ref > ref.max() - 79.9) & (got > got.max() - 79.9)   # off both floors (the empty filter row sits on them)
+        assert live.mean() > 0.98 and np.max(np.abs(got[live] - ref[live])) <= 2e-3
+        assert abs(float(got.max()) - float(ref.max())) <= 1e-3
