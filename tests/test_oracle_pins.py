@@ -441,3 +441,19 @@ def test_stft_mel_db_chain_vs_transformers_spectrogram(clips4):
         live = (ref > ref.max() - 79.9) & (got > got.max() - 79.9)   # off both floors (the empty filter row sits on them)
         assert live.mean() > 0.98 and np.max(np.abs(got[live] - ref[live])) <= 2e-3
         assert abs(float(got.max()) - float(ref.max())) <= 1e-3
+
+
+def test_rms_vs_torch_unfold():
+    """`oracle.silence.rms` = librosa.feature.rms(frame_length, hop_length) with librosa 0.8's defaults (center=True,
+    pad_mode='reflect') against torch: reflect-pad by frame_length // 2 (no edge repeat), `unfold` into frames, root mean square.
+    1 + N // hop frames (101 for the 1 s clip), float32 rounding apart."""
+    import torch
+    from oracle import silence as osil
+    rng = np.random.default_rng(2)
+    for n, fl, hop in ((16000, 400, 160), (12345, 400, 160), (4000, 512, 128)):
+        y = rng.standard_normal(n).astype(np.float32)
+        got = osil.rms(y, fl, hop)
+        yp = torch.nn.functional.pad(torch.from_numpy(y).double()[None, None], (fl // 2, fl // 2), mode="reflect")[0, 0]
+        ref = yp.unfold(0, fl, hop).pow(2).mean(dim=1).sqrt().numpy()
+        assert got.shape == ref.shape == (1 + n // hop,)
+        assert np.max(np.abs(got - ref)) <= 2e-6 * ref.max()
