@@ -610,7 +610,8 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                     if (lane == 0) done[63] = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                // (a.tune bits 9..12, tools/gpu/r3_poll.sh only: extra sleeps per poll -- measured, changes neither time nor count)
+                for (int s = 0; s <= ((a.tune >> 9) & 15); ++s) __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
         };
