@@ -347,16 +347,19 @@ __device__ __forceinline__ void dft25(float2 *x) {
 }
 
 // (at least four waves per SIMD: 128 VGPRs -- at 129 a fourth 256-thread workgroup per CU did not fit)
+template <int ROW>  // float2 pitch of a phase-1 table row: 25, or 40 = the 25 entries and the first 15 again (below)
 __global__ void __launch_bounds__(512, 4)
 stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window, const float2 *__restrict__ twM,
                const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe) {
     // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
     constexpr int M = 200, K = 201;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    v2 *tw = reinterpret_cast<v2 *>(lds);  // M twiddles
-    v2 *tw2 = tw + M;         // M + 1 untangle twiddles
-    v2 *win2 = tw2 + (M + 2); // window as (w[2m], w[2m+1])
-    v2 *Z = win2 + M;         // F frames of kMP400
+    v2 *tw = reinterpret_cast<v2 *>(lds);  // 8 rows of twiddles
+    v2 *tw2 = tw + 8 * ROW;   // M + 1 untangle twiddles
+    v2 *win2 = tw2 + (M + 2); // 8 rows: window as (w[2m], w[2m+1])
+    v2 *Z = win2 + 8 * ROW;   // F frames of kMP400
+    // (ROW == 40) table column of item `it` (= 25 f + n2): n2, + 25 behind a frame change inside the item's 16-lane group
+    auto column = [&](int it, int f, int n2) { return ROW == 25 ? n2 : n2 + 25 * (f - (it & ~15) / 25); };
     const int b = blockIdx.y, t0 = blockIdx.x * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
     const int nthr = blockDim.x;
@@ -368,12 +371,12 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     constexpr int kRounds1 = 3;
     const bool ahead = 25 * nf <= kRounds1 * nthr;
     v2 au[kRounds1][8];
-    int fr_[kRounds1], n2_[kRounds1];
+    int fr_[kRounds1], n2_[kRounds1], col_[kRounds1];
     if (ahead) {
         int f = tid / 25, n2 = tid - (tid / 25) * 25;
 #pragma unroll
         for (int r = 0; r < kRounds1; ++r) {
-            fr_[r] = f, n2_[r] = n2;
+            fr_[r] = f, n2_[r] = n2, col_[r] = column(tid + r * nthr, f, n2);
             const v2 *fr = reinterpret_cast<const v2 *>(clip + (unsigned)(min(f, nf - 1) * hop));
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) au[r][n1] = fr[25 * n1 + n2];
@@ -385,35 +388,40 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     }
     // tw is stored by output index: tw[25 * k1 + n2] = W_200^(n2 k1), so that phase 1's lanes (n2 fastest) read consecutive
     // entries (indexed n2 * k1 the reads were strided by k1: up to 4 lanes per bank)
-    for (int i = tid; i < M; i += nthr) {
-        const int k1 = i / 25;
-        tw[i] = reinterpret_cast<const v2 *>(twM)[(i - 25 * k1) * k1];
-        win2[i] = reinterpret_cast<const v2 *>(window)[i];
+    // ROW == 40: a row holds its 25 entries and the first 15 again.  The table reads are ds_read2_b64, served in groups of 16 lanes
+    // over 32 banks, and a group in which the frame changes (n2 = a .. 24, 0 .. a - 10) meets itself in up to 7 banks -- 270 of the
+    // kernel's 720 conflict cycles per workgroup (simulated per phase; matches SQ_LDS_BANK_CONFLICT / 5120); with the longer rows
+    // such a group reads entries a .. a + 15.
+    for (int i = tid; i < 8 * ROW; i += nthr) {
+        const int k1 = i / ROW, j = i - ROW * k1, n2 = j < 25 ? j : j - 25;
+        tw[i] = reinterpret_cast<const v2 *>(twM)[n2 * k1];
+        win2[i] = reinterpret_cast<const v2 *>(window)[25 * k1 + n2];
     }
     for (int i = tid; i <= M; i += nthr) tw2[i] = reinterpret_cast<const v2 *>(tw2M)[i];
     __syncthreads();
 
     // phase 1
-    auto butterfly1 = [&](v2 (&v)[8], int f, int n2) {
+    auto butterfly1 = [&](v2 (&v)[8], int f, int n2, int j) {  // j: the item's table column
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) v[n1] = v[n1] * win2[25 * n1 + n2];
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = v[n1] * win2[ROW * n1 + j];
         pk_dft8(v);
         v2 *zf = Z + f * kMP400 + n2;
         zf[0] = v[0];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmulp(v[k1], tw[25 * k1 + n2]);
+        for (int k1 = 1; k1 < 8; ++k1) zf[k1 * 25] = cmulp(v[k1], tw[ROW * k1 + j]);
     };
     if (ahead) {
 #pragma unroll
         for (int r = 0; r < kRounds1; ++r)
-            if (fr_[r] < nf) butterfly1(au[r], fr_[r], n2_[r]);
+            if (fr_[r] < nf) butterfly1(au[r], fr_[r], n2_[r], col_[r]);
     } else {
-        for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf;) {
+        int it = tid;
+        for (int f = tid / 25, n2 = tid - (tid / 25) * 25; f < nf; it += nthr) {
             const v2 *fr = reinterpret_cast<const v2 *>(clip + (unsigned)(f * hop));
             v2 v[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) v[n1] = fr[25 * n1 + n2];
-            butterfly1(v, f, n2);
+            butterfly1(v, f, n2, column(it, f, n2));
             n2 += dr1;
             const int carry = n2 >= 25 ? 1 : 0;
             n2 -= 25 * carry;
@@ -498,11 +506,14 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         if (maxf > nthreads / 8) maxf = nthreads / 8;
         const int ntiles = (T + maxf - 1) / maxf;
         const int F = (T + ntiles - 1) / ntiles;
-        const size_t lds = sizeof(float2) * (200 + 202 + 200 + (size_t)F * kMP400);
-        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft400_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int row = 25;
+        if (const char *ev = smh::probe_env("SMH_STFT_ROW")) row = atoi(ev) == 40 ? 40 : 25;
+        const size_t lds = sizeof(float2) * (8 * row + 202 + 8 * row + (size_t)F * kMP400);
+        auto kernel = row == 40 ? stft400_kernel<40> : stft400_kernel<25>;
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((T + F - 1) / F, B), block(nthreads);
         const int probe = smh::probe_env("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
-        hipLaunchKernelGGL(stft400_kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
+        hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
                            ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe);
         return smh::launch_status("stft400_kernel");
     }

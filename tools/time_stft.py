@@ -13,7 +13,10 @@ S = torch.empty((B, 201, 98), device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 run = lambda: _lib.check(fe.lib.smh_stft_mag_f32(fe._h, C.c_void_p(audio.data_ptr()), B, 16000, C.c_void_p(S.data_ptr()), st))
 for cfg in sys.argv[1:] or ["20,256"]:
-    os.environ["SMH_STFT_FRAMES"] = cfg
+    parts = cfg.split(",")
+    os.environ["SMH_STFT_FRAMES"] = ",".join(parts[:2])
+    if len(parts) > 2:  # third field: table row pitch 25 | 40 (probe SMH_STFT_ROW, needs SMH_ENABLE_PROBES=1)
+        os.environ["SMH_STFT_ROW"] = parts[2]
     for _ in range(30): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
