@@ -369,6 +369,8 @@ def main():
         }
         if steady is not None:
             res["steady_state"] = steady
+        if ranks.dist is not None:  # the backend the barrier / MAX / SUM of the timed region went through
+            res["dist_backend"] = ranks.backend
         if "median" in kernels:
             res["hbm_roofline_pct_median_kernel"] = round(100 * kernels["median"]["frac"], 2)
         if cpu is not None:

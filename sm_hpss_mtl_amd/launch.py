@@ -123,8 +123,9 @@ def init_ranks(n_gpus: int, backend=None) -> Ranks:
         if local_rank >= have:
             raise SystemExit("error: rank %d has no GPU (LOCAL_RANK=%d, %d visible)" % (rank, local_rank, have))
         torch.cuda.set_device(local_rank)
-    if world == 1:
+    if world == 1 and not (os.environ.get("SMH_DIST_SINGLE_RANK") == "1" and "MASTER_PORT" in os.environ):
         return Ranks(backend=backend)
+    # (SMH_DIST_SINGLE_RANK=1 under a launcher: a one-rank group, so that barrier / MAX / SUM really go through the backend)
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend == "nccl":

@@ -51,10 +51,13 @@ def _cur_stream():
 
 
 def process_group():
-    """torch.distributed when a process group with more than one rank is initialised, else None."""
+    """torch.distributed when a process group with more than one rank is initialised, else None.  `SMH_DIST_SINGLE_RANK=1` also
+    sends a ONE-rank group through every collective of the data-parallel path (gradient bucket, epoch logs, stop flag, generator
+    state check): on a one-GPU machine that is the only way the RCCL backend itself gets executed (tests)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1 or os.environ.get("SMH_DIST_SINGLE_RANK") == "1":
+            return dist
     return None
 
 
@@ -327,9 +330,9 @@ class TrainingMixin:
     def apply_gradients(self, mask=TRAIN_ALL):
         """All-reduce the bucket [gradient | BatchNorm batch statistics] (if torch.distributed is initialised) -- SUM over
         ranks, the 1/world factor rides in the update --, then clip (after averaging: SURVEY 8e), update, repack."""
-        import torch.distributed as dist
         scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist = process_group()
+        if dist is not None:
             dist.all_reduce(self._bucket_tensor(), op=dist.ReduceOp.SUM)  # ONE flat bucket (0.9 MB) over RCCL
             scale = 1.0 / dist.get_world_size()
         self._apply_native(self.learning_rate(), scale, mask)

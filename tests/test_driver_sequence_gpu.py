@@ -198,6 +198,7 @@ def _dp_fit_worker(rank, world, port, tmp, q):
         PARAMS = _params(tmp / ("rank%d" % rank), folder, train, test)
         PARAMS.update(epochs=3, TR_STEPS=3, V_STEPS=1, batch_size=8)
         np.random.seed(11)                                     # the caller seeds every rank alike (one global batch, rows shared out)
+        torch.manual_seed(5)                                   # (the device-side noise augmentation draws from torch's generator)
         model, _ = get_Lemaire_MTL_model(TR_STEPS=3, N_MELS=240, n_classes=3, patch_size=68, seed=4)
         base = str(tmp / "dp_model")                            # ONE path for both ranks: only rank 0 may write it
         model, History = _train_model(PARAMS, model, base + ".h5", base + "_log.csv")
@@ -228,3 +229,65 @@ def test_two_rank_fit_keeps_replicas_identical_and_logs_global(tmp_path):
     for a, b in zip(w0, w1):
         assert np.array_equal(a, b)        # replicas identical after 9 steps + whatever the callbacks restored
     assert os.path.exists(tmp_path / "dp_model.h5") and len(open(tmp_path / "dp_model_log.csv").read().strip().splitlines()) == 4
+
+
+# ---- RCCL itself, on the one GPU a test box has ---------------------------------------------------------------------------------
+def test_one_rank_fit_runs_every_dp_collective_on_rccl(tmp_path, monkeypatch):
+    """World size 2 needs two GPUs for RCCL (one rank per device); a one-GPU box therefore runs the two-rank test above on gloo and
+    never loads the backend the product names.  With SMH_DIST_SINGLE_RANK=1 a ONE-rank 'nccl' group takes the same code path: the
+    gradient bucket all-reduce, the epoch-log all-reduce + broadcast, the stop-flag MAX and the generator's state check all go
+    through RCCL on device tensors.  The result must EQUAL a run without any process group (sums over one rank, scale 1;
+    deterministic gradient sums switched on for both)."""
+    import socket
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("SMH_DIST_SINGLE_RANK", "1")
+    monkeypatch.setenv("SMH_DETERMINISTIC", "1")   # fixed-point gradient sums: the two runs are comparable bit for bit
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_fit_worker, args=(0, 1, port, str(tmp_path), q))
+    p.start()
+    _, backend, h_dp, w_dp = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl"
+    # the same fit in this process, no process group
+    monkeypatch.delenv("SMH_DIST_SINGLE_RANK")
+    from lib.proposed_architectures import get_Lemaire_MTL_model
+    folder, train, test = _folds(tmp_path / "solo", n_files=8, seed=3)
+    PARAMS = _params(tmp_path / "solo", folder, train, test)
+    PARAMS.update(epochs=3, TR_STEPS=3, V_STEPS=1, batch_size=8)
+    np.random.seed(11)
+    torch.manual_seed(5)
+    model, _ = get_Lemaire_MTL_model(TR_STEPS=3, N_MELS=240, n_classes=3, patch_size=68, seed=4)
+    model, History = _train_model(PARAMS, model, str(tmp_path / "solo_model.h5"), str(tmp_path / "solo_log.csv"))
+    assert h_dp.keys() == History.history.keys()
+    for k in h_dp:
+        assert h_dp[k] == History.history[k], k
+    for a, b in zip(w_dp, model.get_weights()):
+        assert np.array_equal(a, b)
+    assert os.path.exists(tmp_path / "dp_model.h5")
+
+
+def test_bench_under_a_launcher_goes_through_rccl_on_one_rank():
+    """bench.py as the driver starts it for N > 1 (RANK / WORLD_SIZE / MASTER_* in the environment), with one rank and
+    SMH_DIST_SINGLE_RANK=1: barrier + MAX + SUM of the timed region run on RCCL; the JSON line is the N = 1 line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SMH_DIST_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_DISTRIBUTED_DEBUG="INFO")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--steady-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["ranks_reporting"] == 1 and line["value"] > 0 and line["parity"]["checked"]
+    assert line.get("dist_backend") == "nccl"
