@@ -343,6 +343,20 @@ int smh_cnn_train_step_f32(smh_cnn_trainer *t, const float *d_x, const float *d_
 int smh_cnn_trainer_apply_f32(smh_cnn_trainer *t, int optimizer, float lr, float beta1, float beta2, float eps,
                               float grad_scale, void *stream);
 
+/* ---- a15: the random draws of a training batch, one pass each (csrc/smh_rng.hip) ------------------------------------
+ * Philox4x32-10 keyed by `seed`; `offset` selects an independent stream under the same seed (pass a per-call counter):
+ * equal (seed, offset, n) give equal output, on any launch geometry.
+ * smh_noise_augment_f32: d_out[i] = d_x[i] + N(0, scale) -- the generator's noise augmentation,
+ *   Proposed_Work_Results.py:239-242 (np.random.normal(0, scale, shape) + np.add; the scale is drawn by the caller).
+ *   d_out may be d_x (in place).  Both 16-byte aligned.
+ * smh_dropout_masks_f32: d_out[0 .. n_a) = (u < keep_a ? 1 / keep_a : 0), d_out[n_a .. n_a + n_b) likewise with keep_b:
+ *   the SpatialDropout1D masks (N, n_blocks, 32) and the heads' Dropout(0.4) masks (N, n_heads, 16) that
+ *   smh_train_step_f32 takes, in one launch.                                                                          */
+int smh_noise_augment_f32(const float *d_x, float *d_out, size_t n, float scale, unsigned long long seed,
+                          unsigned long long offset, void *stream);
+int smh_dropout_masks_f32(float *d_out, size_t n_a, float keep_a, size_t n_b, float keep_b, unsigned long long seed,
+                          unsigned long long offset, void *stream);
+
 /* ---- a14: one training step = what model.fit runs per batch (Proposed_Work_Results.py:298-307) for the
  * model compiled at lib/proposed_architectures.py:156-165: BCE (S, M[, N]) + MSE (R) + CCE (3C) with optional
  * loss_weights, l2(0.01) on the Dense(16) kernels, SGD(momentum, clipnorm, lr from ExponentialDecay).

@@ -71,6 +71,8 @@ SIGNATURES = {
     "smh_preprocess_signal_f32": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp, _vp, _sz, _vp]),
     "smh_mix_signals_f32": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "smh_medfilt1d_f32": (_i, [_fp, _i, _i, _i, _fp, _vp]),
+    "smh_noise_augment_f32": (_i, [_fp, _fp, _sz, C.c_float, C.c_ulonglong, C.c_ulonglong, _vp]),
+    "smh_dropout_masks_f32": (_i, [_fp, _sz, C.c_float, _sz, C.c_float, C.c_ulonglong, C.c_ulonglong, _vp]),
     "smh_cnn_trainer_create": (_i, [_vp, _i, C.POINTER(C.c_void_p)]),
     "smh_cnn_trainer_destroy": (None, [_vp]),
     "smh_cnn_trainer_grad_ptr": (_vp, [_vp]),

@@ -53,14 +53,13 @@ def make_labels_5class(bs: int, smr_spmu_db, smr_spno_db):
 
 
 def noise_augmentation(batch, rng):
-    """batch + N(0, scale), scale drawn once per batch (works on numpy arrays and torch tensors)."""
+    """batch + N(0, scale), scale drawn once per batch from `rng` (Proposed_Work_Results.py:239-242).  Host batches (numpy) draw
+    the noise from `rng` too; device batches (float32 CUDA tensors) get it from the HIP kernel in one pass over the patches
+    (device_rng.add_normal_noise: Philox, seeded from torch's generator) -- there is no torch fallback for a device batch."""
     scale = float(rng.choice(NOISE_SCALES))
-    try:
-        import torch
-        if isinstance(batch, torch.Tensor):
-            return batch + scale * torch.randn(batch.shape, device=batch.device, dtype=batch.dtype)
-    except ImportError:  # pragma: no cover
-        pass
+    if not isinstance(batch, np.ndarray):
+        from .device_rng import add_normal_noise
+        return add_normal_noise(batch, scale)
     return batch + rng.normal(0.0, scale, size=batch.shape)
 
 

@@ -124,8 +124,8 @@ class TrainingMixin:
         # lib/proposed_architectures.py:156-158
         self.optimizer = _opt.SGD(learning_rate=_opt.ExponentialDecay(self.initial_learning_rate, 3 * max(int(self.TR_STEPS), 1), 0.1),
                                   clipnorm=1, momentum=0.9)
-        self._rng = torch.Generator(device="cuda")
-        self._rng.manual_seed(1234 + int(os.environ.get("RANK", "0")))  # data parallel: every rank draws its own masks
+        self._mask_seed = 1234 + int(os.environ.get("RANK", "0"))  # data parallel: every rank draws its own masks
+        self._mask_calls = 0
         # bit-reproducible weight gradients (include/smh.h: smh_trainer_set_deterministic); SMH_DETERMINISTIC=1 turns it on for
         # every model of the process, `model.deterministic_gradients = True` for one
         self._deterministic = os.environ.get("SMH_DETERMINISTIC", "0") == "1"
@@ -291,26 +291,17 @@ class TrainingMixin:
         self._sync_weights()
         tr = self._get_trainer(n)
         n_blocks, n_heads = self.nb_stacks * self.n_dilations, len(self.output_names) - 1
-        if isinstance(drop_tcn, str) and isinstance(drop_heads, str):
-            # both masks from ONE Bernoulli draw and one scaling (two kernels instead of eight): cached per batch size are the keep
-            # probabilities [trunk | heads] and their reciprocals
-            cache = self.__dict__.setdefault("_drop_cache", {})
-            if n not in cache:
-                n_t, n_h = n * n_blocks * 32, n * n_heads * 16
-                prob = torch.empty(n_t + n_h, dtype=torch.float32, device="cuda")
-                prob[:n_t] = 1.0 - self.dropout_rate
-                prob[n_t:] = 1.0 - HEAD_DROPOUT
-                cache.clear()
-                cache[n] = (prob, 1.0 / prob, n_t)
-            prob, scale, n_t = cache[n]
-            masks = torch.bernoulli(prob, generator=self._rng).mul_(scale)
-            drop_tcn, drop_heads = masks[:n_t].view(n, n_blocks, 32), masks[n_t:].view(n, n_heads, 16)
-        if isinstance(drop_tcn, str):
-            keep = 1.0 - self.dropout_rate
-            drop_tcn = torch.empty((n, n_blocks, 32), device="cuda").bernoulli_(keep, generator=self._rng).div_(keep)
-        if isinstance(drop_heads, str):
-            keep = 1.0 - HEAD_DROPOUT
-            drop_heads = torch.empty((n, n_heads, 16), device="cuda").bernoulli_(keep, generator=self._rng).div_(keep)
+        if isinstance(drop_tcn, str) or isinstance(drop_heads, str):
+            # both masks from ONE launch (csrc/smh_rng.hip; until round 3 a torch Bernoulli draw and a scaling): Philox keyed by this
+            # replica's seed (1234 + RANK: every rank draws its own masks), one stream per step
+            from .device_rng import dropout_masks
+            n_t, n_h = n * n_blocks * 32, n * n_heads * 16
+            masks = dropout_masks(n_t, 1.0 - self.dropout_rate, n_h, 1.0 - HEAD_DROPOUT, self._mask_seed, self._mask_calls)
+            self._mask_calls += 1
+            if isinstance(drop_tcn, str):
+                drop_tcn = masks[:n_t].view(n, n_blocks, 32)
+            if isinstance(drop_heads, str):
+                drop_heads = masks[n_t:].view(n, n_heads, 16)
         losses = torch.empty(self._n_losses(), dtype=torch.float32, device="cuda")
         p = lambda t: None if t is None else C.c_void_p(t.contiguous().data_ptr())  # noqa: E731
         _lib.check(self.lib.smh_train_step_f32(tr, p(x), p(yt), n, p(drop_tcn), p(drop_heads), self._loss_weight_array(_only),

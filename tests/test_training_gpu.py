@@ -165,7 +165,7 @@ def _dp_worker(rank, world, port, q):
     for _ in range(2):
         m.train_on_batch(x[sl], yl, drop_tcn=None, drop_heads=None)
     got = m.get_weights_dict()
-    seed_probe = float(torch.rand(1, device="cuda", generator=m._rng).item())  # the ranks' dropout streams must differ
+    seed_probe = float(m._mask_seed)  # the ranks' dropout streams (Philox key 1234 + RANK) must differ
     q.put((rank, {k: v.copy() for k, v in got.items()}, seed_probe))
     dist.destroy_process_group()
 

@@ -52,6 +52,7 @@ def main():
     import numpy as np
     import torch
     from sm_hpss_mtl_amd.batching import make_labels_3class, make_labels_5class
+    from sm_hpss_mtl_amd.device_rng import add_normal_noise
     from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
     from sm_hpss_mtl_amd.model import B3MTL
     from sm_hpss_mtl_amd.synth import synth_clips
@@ -81,7 +82,9 @@ def main():
         res = fe.run(audio, W=W, shift=shift, out=out)
         out.update(fv=res["fv"], patches=res["patches"])
         x = res["patches"]
-        return x.add_(torch.randn_like(x), alpha=1e-3)  # noise_augmentation, in place on the patches this step produced (Proposed_Work_Results.py:239-242; scale drawn from {5e-3, 1e-3, 5e-4, 1e-4} there)
+        # noise_augmentation, in place on the patches this step produced (Proposed_Work_Results.py:239-242; scale drawn from
+        # {5e-3, 1e-3, 5e-4, 1e-4} there): one HIP pass (csrc/smh_rng.hip); the seed is fixed here so that no host draw sits in the step
+        return add_normal_noise(x, 1e-3, seed=99, out=x)
 
     def step(timed=False):  # the serial form: also what the stage breakdown below is measured on
         if timed:
