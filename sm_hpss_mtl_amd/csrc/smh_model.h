@@ -27,6 +27,7 @@ struct TcnArgs {
     int tune;     // experiment switches of the skewed schedule (SMH_TCN_TUNE; tools only)
     int *status;  // device error word of the model (smh_model_status): bit 0 = a wave of the skewed schedule gave up on a dependency
     int spin_limit;  // polls before a wave of the skewed schedule gives up (kSkewSpinLimit; lowered only by the debug knob of the test)
+    int split_last;  // barrier schedule, two register sets: the last column tile is computed by TWO waves, 16 output channels each (smh_tcn.hip: half_tile_compute)
     int from_x0;  // X holds the two per-half partials of layer 0, (N, 2, T, 32) (smh_features_l0_f32), instead of patches
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];

@@ -121,6 +121,8 @@ struct TileInfo {
     int t[kMaxTiles];   // frame index of row min(R, GR - 1) inside its patch
     int g[kMaxTiles];   // its patch inside the workgroup (SpatialDropout1D masks, training only)
     int n;              // tiles of this wave
+    int hrole;          // -1, or 0 / 1: this wave computes that half of the last tile (TcnArgs::split_last)
+    int hR, ht, hg;     // ... whose row / frame / patch of this lane are these
 };
 
 // Prefetch of the NEXT block's weights (LDS -> the other register set) in four chunks of five ds_read_b128, issued at
@@ -260,12 +262,90 @@ __device__ __forceinline__ void tile_compute(const BlockW &w, int d, bool side_t
     *reinterpret_cast<f32x4 *>(dst + 16) = o1;
 }
 
+// The LAST column tile of a block shared by two waves on different SIMDs (TcnArgs::split_last): wave H = 0 / 1 computes output
+// channels 16 H .. 16 H + 15 -- the accumulator chain acc0 / acc1 of tile_compute, the same products in the same order, so
+// the results are bit-identical to the undivided tile.  With 5 tiles on 8 waves (one 68-frame patch per workgroup: every batch
+// up to 256 patches, BASELINE config 3) the fifth tile was a second full tile on SIMD 0 while three waves idled; as halves on
+// two otherwise idle waves the busiest SIMD runs 96 instead of 128 matrix instructions per block.  What the halves owe each
+// other is the relu'd dilated-conv output (the channel maximum runs over all 32 channels, and the 1x1 conv's k runs over all 32):
+// 16 bytes per lane each way through `xch`, ordered by one flag word per half that carries the block number.
+// epoch = block + 1; xflag[0..1] zeroed before the first block; the per-block barrier keeps the epochs of the two waves in step.
+template <bool TRAIN, int H>
+__device__ __forceinline__ void half_tile_compute(const BlockW &w, int d, bool side_taps, int T, int GR, int ZR, int R, int t, int g,
+                                                  int q, int lane, const float *__restrict__ xin, float *__restrict__ xout,
+                                                  const float *__restrict__ drop, int dstride, float *__restrict__ ub, int ustride,
+                                                  float *__restrict__ xch, int epoch, int spin_limit, int *status) {
+    const int Rc = min(R, GR - 1);
+    f32x4 b[3][2];
+    bool any_tap[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int off = (tap - 1) * d;
+        const bool ok = (tap == 1) || (side_taps && (t + off >= 0) && (t + off < T));
+        any_tap[tap] = (tap == 1) || (side_taps && __any(ok));
+        const float *src = xin + (size_t)(ok ? Rc + off : ZR) * SX + 8 * q;
+        b[tap][0] = *reinterpret_cast<const f32x4 *>(src);
+        b[tap][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+    }
+    f32x4 o = *reinterpret_cast<const f32x4 *>(xin + (size_t)Rc * SX + 4 * q + 16 * H);
+    f32x4 acc = H ? w.b1hi : w.b1lo;
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+        const int tap = ti == 0 ? 1 : (ti == 1 ? 0 : 2);
+        if (!any_tap[tap]) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(w.wc[tap * 8 + 4 * h + s4][H], b[tap][h][s4], acc);
+    }
+    if constexpr (TRAIN) {
+        if (ub && R < GR) *reinterpret_cast<f32x4 *>(ub + (unsigned)(g * ustride + t * C + 4 * q) + 16 * H) = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    // hand this half over, take the other
+    __attribute__((address_space(3))) volatile int *xflag = (__attribute__((address_space(3))) volatile int *)(xch + 2 * 64 * 4);
+    *reinterpret_cast<f32x4 *>(xch + (size_t)(H * 64 + lane) * 4) = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) xflag[H] = epoch;
+    for (int spins = 0; xflag[1 - H] < epoch; ++spins) {
+        if (spins > spin_limit) {  // cannot happen while both waves run the block; never hang the grid on it
+            if (lane == 0 && status) atomicOr(status, 1);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    const f32x4 other = *reinterpret_cast<const f32x4 *>(xch + (size_t)((1 - H) * 64 + lane) * 4);
+    const f32x4 a0 = H ? other : acc, a1 = H ? acc : other;  // channels 4q + r and 16 + 4q + r, as tile_compute holds them
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(a0[r], a1[r]));
+    mx = quad_max(mx);
+    const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
+    f32x4 dm0 = {1.f, 1.f, 1.f, 1.f}, dm1 = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (TRAIN) {
+        if (drop) {
+            const unsigned dofs = (unsigned)(g * dstride + 4 * q);
+            dm0 = *reinterpret_cast<const f32x4 *>(drop + dofs);
+            dm1 = *reinterpret_cast<const f32x4 *>(drop + dofs + 16);
+        }
+    }
+    o += H ? w.b2hi : w.b2lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o = mfma4(w.wp[r][H], a0[r] * inv * dm0[r], o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o = mfma4(w.wp[4 + r][H], a1[r] * inv * dm1[r], o);
+    *reinterpret_cast<f32x4 *>(xout + (size_t)R * SX + 4 * q + 16 * H) = o;
+}
+
 // one residual block for this wave's column tiles (barrier-per-block schedule); prefetch: see WeightPrefetch
 template <bool TRAIN, class PF>
 __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int ZR, const TileInfo &ti, int q,
                                           const float *__restrict__ xin, float *__restrict__ xout,
                                           const float *__restrict__ drop, int dstride, float *__restrict__ ub, int ustride,
-                                          PF prefetch) {
+                                          PF prefetch, int lane = 0, float *__restrict__ xch = nullptr, int epoch = 0,
+                                          int spin_limit = 0, int *status = nullptr) {
     const bool side_taps = d < T;  // |offset| >= T: the side taps only ever see zero padding
     auto tile = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -278,6 +358,12 @@ __device__ __forceinline__ void run_block(BlockW &w, int d, int T, int GR, int Z
     if (ti.n > 2) tile(std::integral_constant<int, 2>{});
     if (ti.n > 3) tile(std::integral_constant<int, 3>{});
     prefetch.rest(ti.n);
+    if (ti.hrole == 0)  // (wave-uniform)
+        half_tile_compute<TRAIN, 0>(w, d, side_taps, T, GR, ZR, ti.hR, ti.ht, ti.hg, q, lane, xin, xout, drop, dstride, ub, ustride, xch,
+                                    epoch, spin_limit, status);
+    else if (ti.hrole == 1)
+        half_tile_compute<TRAIN, 1>(w, d, side_taps, T, GR, ZR, ti.hR, ti.ht, ti.hg, q, lane, xin, xout, drop, dstride, ub, ustride, xch,
+                                    epoch, spin_limit, status);
 }
 
 // MODE: how the 24 residual blocks are scheduled over the waves (launch_forward chooses)
@@ -423,13 +509,23 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     // this wave's column tiles and the zero rows
     TileInfo ti;
     ti.n = 0;
+    // (split_last: the last tile belongs to no wave's list; waves (units - 1) % nw and the next one take a half each)
+    const bool split = MODE == kPrefetch && a.split_last && units >= 2;
 #pragma unroll
     for (int i = 0; i < kMaxTiles; ++i) {
         const int u = wave + i * nw;
         const int R = 16 * u + j, Rc = min(R, GR - 1);
         ti.R[i] = R, ti.g[i] = Rc / T, ti.t[i] = Rc - ti.g[i] * T;
-        if (u < units) ti.n = i + 1;
+        if (u < units - (split ? 1 : 0)) ti.n = i + 1;
     }
+    {
+        const int hw0 = (units - 1) % nw, hw1 = (hw0 + 1) % nw;
+        ti.hrole = split ? (wave == hw0 ? 0 : (wave == hw1 ? 1 : -1)) : -1;
+        const int R = 16 * (units - 1) + j, Rc = min(R, GR - 1);
+        ti.hR = R, ti.hg = Rc / T, ti.ht = Rc - ti.hg * T;
+    }
+    float *xch = lds + 2 * (size_t)(a.GRP + 1) * SX + 2 * (size_t)kBlockFloats;  // behind the weight slots: 2 x 64 x 16 bytes + the flags
+    if (split && threadIdx.x < 2) reinterpret_cast<int *>(xch + 2 * 64 * 4)[threadIdx.x] = 0;
     if (threadIdx.x < SX) xa[(size_t)ZR * SX + threadIdx.x] = 0.f, xb[(size_t)ZR * SX + threadIdx.x] = 0.f;
     float *xin = xa, *xout = xb;
     const int nslot = a.n_blocks + 1;
@@ -450,7 +546,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
     auto one_block = [&](int blk, BlockW &w, auto prefetch) {
         save_acts(xin, blk);
         run_block<TRAIN>(w, 1 << (blk % a.n_dil), T, GR, ZR, ti, q, xin, xout, drop0 ? drop0 + (size_t)blk * C : nullptr, dstride,
-                         ub0 ? ub0 + (size_t)blk * T * C : nullptr, ustride, prefetch);
+                         ub0 ? ub0 + (size_t)blk * T * C : nullptr, ustride, prefetch, lane, xch, blk + 1, a.spin_limit, a.status);
         float *tmp = xin;
         xin = xout;
         xout = tmp;
@@ -1055,8 +1151,10 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     GRP = ((GRP + 15) / 16) * 16;
     a.GRP = GRP;
     const size_t lds_x = sizeof(float) * 2 * (size_t)(GRP + 1) * SX, lds_w = sizeof(float) * 2 * (size_t)kBlockFloats;  // + the zero rows
-    a.wlds = lds_x + lds_w <= 156 * 1024 ? 1 : 0;  // activations (x2) + two weight slots, when they fit
-    *plds = lds_x + (a.wlds ? lds_w : 0);
+    const size_t lds_xch = sizeof(float) * (2 * 64 * 4 + 4);  // the exchange area of split_last (half_tile_compute)
+    a.wlds = lds_x + lds_w + lds_xch <= 156 * 1024 ? 1 : 0;  // activations (x2) + two weight slots, when they fit
+    a.split_last = 0;
+    *plds = lds_x + (a.wlds ? lds_w + lds_xch : 0);
 }
 
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
@@ -1107,6 +1205,10 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     bool skew16 = false;
     if (const char *ev = getenv("SMH_TCN_SKEW16")) skew16 = atoi(ev) != 0 && skew && !tio && !a.trace && lds16 <= 156 * 1024;
     if (skew16) nwaves = 16, lds = lds16;
+    // barrier schedule with two register sets and ONE tile in its last round (5, 9, ... tiles on 8 waves): that tile as two halves on
+    // two waves of different SIMDs (half_tile_compute).  SMH_TCN_SPLIT=0 switches it off (tests: the two forms agree bit for bit).
+    a.split_last = (!skew && prefetch && nwaves == 8 && units >= 2 && (units % 8 == 1 || units % 8 == 5)) ? 1 : 0;
+    if (const char *ev = getenv("SMH_TCN_SPLIT")) a.split_last = a.split_last && atoi(ev) != 0;
     const dim3 grid((N + a.G - 1) / a.G), block(64 * nwaves);
     TrainIO io{nullptr, nullptr, nullptr, nullptr};
     if (tio) io = *tio;

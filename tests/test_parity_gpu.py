@@ -360,6 +360,15 @@ def test_b3mtl_block_schedules_agree(W, N, monkeypatch):
     # schedule its batch size selects
     assert np.array_equal(outs["2"][0], outs["0"][0]) and np.array_equal(outs["2"][1], outs["0"][1])
     assert np.array_equal(outs["16"][0], outs["0"][0]) and np.array_equal(outs["16"][1], outs["0"][1])
+    # the barrier schedule gives a lone last-round tile to two waves, 16 output channels each (5, 9, 13, 17 tiles): without the
+    # split (SMH_TCN_SPLIT=0) the same bits
+    monkeypatch.setenv("SMH_TCN_SKEW", "0")
+    monkeypatch.setenv("SMH_TCN_SPLIT", "0")
+    trunk = torch.empty((N, W, 32), device="cuda")
+    whole = (host(m.forward_device(x, trunk=trunk)), host(trunk))
+    m.check_status()
+    monkeypatch.delenv("SMH_TCN_SPLIT")
+    assert np.array_equal(whole[0], outs["0"][0]) and np.array_equal(whole[1], outs["0"][1])
     sel = np.unique(np.r_[0:min(4, N), max(0, N - 4):N])
     ref = np.concatenate(b3_mtl.forward(host(x)[sel], w, n_classes=3), axis=1)
     for skew in ("2", "0"):

@@ -27,4 +27,15 @@ for n in sizes:
         b.record()
         torch.cuda.synchronize()
         res[sk] = a.elapsed_time(b) / 60 * 1e3
-    print("W=%d N=%5d  skew %8.1f us   barrier %8.1f us   default %8.1f us" % (W, n, res["2"], res["0"], res["1"]), flush=True)
+    # the barrier schedule without the two-wave split of a lone last-round tile (SMH_TCN_SPLIT=0)
+    os.environ["SMH_TCN_SKEW"], os.environ["SMH_TCN_SPLIT"] = "0", "0"
+    for _ in range(20):
+        m.forward_device(x, out=out)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(60):
+        m.forward_device(x, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    del os.environ["SMH_TCN_SPLIT"]
+    print("W=%d N=%5d  skew %8.1f us   barrier %8.1f us (unsplit %8.1f)   default %8.1f us" % (W, n, res["2"], res["0"], a.elapsed_time(b) / 60 * 1e3, res["1"]), flush=True)
