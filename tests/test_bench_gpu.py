@@ -75,3 +75,20 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr and '{"metric"' not in r.stdout
+
+
+def test_bench_two_ranks_run_the_real_path_and_report_the_whole_job():
+    """`bench.py --gpus 2` as it launches itself (parent -> torch.distributed.run -> two ranks), with the collectives on gloo so
+    that the two ranks can share the test box's one GPU: each rank runs the real hot path on its OWN 1024-clip shard, rank 0's line
+    counts both (value = 2 x B x K / the slower rank's time) and every rank's logits were held against the golden."""
+    env = dict(os.environ, SMH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "128",
+                        "--steady-steps", "0", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reporting"] == 2 and d["scaling"] == "weak" and d["dist_backend"] == "gloo"
+    assert d["value"] == pytest.approx(2 * 128 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-3)
+    assert d["parity"]["checked"] and d["parity"]["ranks_without_golden_check"] == 0
+    assert "cpu_baseline" not in d   # rank 0 at N = 1 only
