@@ -390,6 +390,7 @@ struct BwdArgs {
     unsigned long long *gq;  // deterministic mode: the fixed-point accumulators (n_params), else nullptr
     int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
     int stamps;  // tools only (SMH_BWD_STAMPS): workgroup 0 prints the time its phases took, summed over the blocks
+    int split3;  // MFMA kernel: a lone last-round tile of phase 3 is shared by two waves (SMH_BWD_SPLIT=0 switches it off: A/B and tests)
     int use_wt;  // VALU kernel: keep transposed LDS copies of the block kernels (0 for patches so long that they do not fit)
     Offsets off;
 };
@@ -622,7 +623,8 @@ __device__ __forceinline__ float quad_reduce(float v, F f) {
 // WLDS: the block's canonical kernels are parked in LDS.  Patches longer than 128 frames (the reference's W = 249) leave no room
 // for them next to the four activation images: WLDS = false reads them from the weight vector itself.
 template <bool WLDS, int MAXT>
-__global__ void __launch_bounds__(kMThreads)
+// (WLDS: held to 128 VGPRs = four waves per SIMD = two workgroups per CU; at 129 the second workgroup is lost and the step costs 100 us more)
+__global__ void __launch_bounds__(kMThreads, WLDS ? 4 : 1)
 tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw,
                          const float *__restrict__ acts, const float *__restrict__ drop, const float *__restrict__ dpre,
                          float *__restrict__ grad, int RPm, const float *__restrict__ upre) {
@@ -928,14 +930,21 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
         lap(2);
         if (blk > 0) prefetch_u(blk - 1);
         // ---- phase 3: g[time][c] += sum_tap sum_co W1[tap][c][co] du[time - off][co] ---------------------------------
-        for (int u = wave; u < units; u += nw) {
+        // A lone tile in the last round of the eight waves (5 tiles: one 68-frame patch; 9, 13) is a second whole tile on one SIMD
+        // while three waves idle: its two accumulator chains (channels 0-15, 16-31) are independent, so two waves on different SIMDs
+        // take one each -- same products, same order, same bits; the busiest SIMD runs 72 instead of 96 products per block.
+        const bool split3 = a.split3 && nw == 8 && (units & 3) == 1 && units >= 2;
+        const int hw0 = (units - 1) & 7, hw1 = (hw0 + 1) & 7;
+        auto phase3_tile = [&](int u, auto part_c) {
+            constexpr int PART = decltype(part_c)::value;  // 0: both channel halves, 1: channels 0-15, 2: channels 16-31
             const int R = 16 * u + j;
-            if (16 * u >= rows) continue;
+            if (16 * u >= rows) return;
             const bool live = R < rows;
             const int Rc = min(R, rows - 1);
             const int t = Rc % T;
-            f32x4 g0 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 4 * q);
-            f32x4 g1 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 16 + 4 * q);
+            f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+            if (PART != 2) g0 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 4 * q);
+            if (PART != 1) g1 = *reinterpret_cast<const f32x4 *>(G + (size_t)Rc * SX + 16 + 4 * q);
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int off = (tap - 1) * d;
@@ -944,19 +953,25 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
                 const float *src = (ok ? DU + (size_t)(Rc - off) * SX : ZW) + 8 * q;
                 const f32x4 bA = *reinterpret_cast<const f32x4 *>(src), bB = *reinterpret_cast<const f32x4 *>(src + 4);
                 const float *wa = W1p + (size_t)(tap * C + j) * WS + 8 * q;  // W1[tap][c = j (+16)][co = 8 q + s8]
-                const f32x4 a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
-                const f32x4 a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
+                f32x4 a0A = {0.f, 0.f, 0.f, 0.f}, a0B = a0A, a1A = a0A, a1B = a0A;
+                if (PART != 2) a0A = *reinterpret_cast<const f32x4 *>(wa), a0B = *reinterpret_cast<const f32x4 *>(wa + 4);
+                if (PART != 1) a1A = *reinterpret_cast<const f32x4 *>(wa + 16 * WS), a1B = *reinterpret_cast<const f32x4 *>(wa + 16 * WS + 4);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const float bv = s8 < 4 ? bA[s8 & 3] : bB[s8 & 3];
-                    g0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, g0);
-                    g1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, g1);
+                    if (PART != 2) g0 = mfma4(s8 < 4 ? a0A[s8 & 3] : a0B[s8 & 3], bv, g0);
+                    if (PART != 1) g1 = mfma4(s8 < 4 ? a1A[s8 & 3] : a1B[s8 & 3], bv, g1);
                 }
             }
             if (live) {
-                *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 4 * q) = g0;
-                *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 16 + 4 * q) = g1;
+                if (PART != 2) *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 4 * q) = g0;
+                if (PART != 1) *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + 16 + 4 * q) = g1;
             }
+        };
+        for (int u = wave; u < units - (split3 ? 1 : 0); u += nw) phase3_tile(u, std::integral_constant<int, 0>{});
+        if (split3) {  // (wave-uniform)
+            if (wave == hw0) phase3_tile(units - 1, std::integral_constant<int, 1>{});
+            else if (wave == hw1) phase3_tile(units - 1, std::integral_constant<int, 2>{});
         }
     }
     __syncthreads();
@@ -1388,6 +1403,8 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     if (rc) return rc;
     BwdArgs ba;
     ba.gq = t->d_gq;  // nullptr unless smh_trainer_set_deterministic(t, 1)
+    ba.split3 = 1;
+    if (const char *ev = getenv("SMH_BWD_SPLIT")) ba.split3 = atoi(ev) != 0;
     ba.N = N, ba.T = m->cfg.patch_size, ba.F = m->cfg.n_feat, ba.n_blocks = m->n_blocks, ba.n_dil = m->cfg.n_dilations;
     ba.use_wt = 1;
     ba.stamps = getenv("SMH_BWD_STAMPS") ? 1 : 0;

@@ -1,5 +1,6 @@
 """GPU: the HIP training step (forward-train, losses, backward, SGD) against the numpy oracle, which is itself
 pinned against torch autograd on the CPU (tests/test_oracle_train.py)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -307,6 +308,14 @@ def test_deterministic_gradients_are_bit_reproducible(ncls, N):
             mm.train_on_batch(x, y, drop_tcn=dt, drop_heads=dh)
         ends.append(mm.get_weights())
     assert all(np.array_equal(a, b) for a, b in zip(*ends))
+    # the shared last tile (forward: two half tiles; backward phase 3: one accumulator chain per wave) adds the same products
+    # in the same order: with both switched off the deterministic gradient is the same, bit for bit
+    os.environ["SMH_TCN_SPLIT"], os.environ["SMH_BWD_SPLIT"] = "0", "0"
+    try:
+        whole = grad()
+    finally:
+        del os.environ["SMH_TCN_SPLIT"], os.environ["SMH_BWD_SPLIT"]
+    assert torch.equal(whole, det[0])
 
 
 def test_growing_the_trainer_keeps_the_optimiser_state():
