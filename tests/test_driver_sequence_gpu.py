@@ -99,7 +99,10 @@ def _train_model(PARAMS, model, weightFile, logFile):
     return model, History
 
 
-def test_build_fit_save_reload_filewise_test_and_score(tmp_path):
+def test_build_fit_save_reload_filewise_test_and_score(tmp_path, monkeypatch):
+    # a reproducible run: numpy and torch seeded, weight-gradient sums in fixed point -- the assertions below see the same numbers every time
+    monkeypatch.setenv("SMH_DETERMINISTIC", "1")
+    torch.manual_seed(0)
     from lib.proposed_architectures import get_Lemaire_MTL_model, model_from_json   # the reference's import path
     from sm_hpss_mtl_amd import optimizers
     from sm_hpss_mtl_amd.generators import test_file_wise_generator
