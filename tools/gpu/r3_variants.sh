@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 3: the parity suites under the alternative implementations (environment switches of INTEGRATION.md): every variant must pass
+# (tests that assert WHICH implementation was chosen are expected to object when a switch forces another one: listed, not hidden)
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r3
+run() {  # name, env...
+  name=$1; shift
+  env "$@" timeout -k 10 600 python -m pytest tests/test_parity_gpu.py tests/test_bench_path_gpu.py tests/test_ragged_gpu.py tests/test_inference_gpu.py -q -p no:cacheprovider > gpurun_out/r3/variant_$name.log 2>&1
+  echo "$name rc=$? $(tail -1 gpurun_out/r3/variant_$name.log)"; grep "^FAILED" gpurun_out/r3/variant_$name.log | cut -c1-160
+}
+if [ "$1" = all ]; then
+run skew2 SMH_TCN_SKEW=2
+run skew0_nosplit SMH_TCN_SKEW=0 SMH_TCN_SPLIT=0
+run feat_nopair SMH_FEAT_NOPAIR=1
+run stft_generic SMH_STFT_GENERIC=1
+fi
+run feat_two_kernels SMH_FEAT_TWO_KERNELS=1
+run median_nosplit SMH_MEDIAN_NOSPLIT=1
+run median_persist SMH_MEDIAN_PERSIST=1
+run feat_taps SMH_FEAT_TAPS=1
