@@ -714,6 +714,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         // the task counter (done[62], starts at the number of waves: wave w begins with task w).  A wave takes its next task
         // late -- behind the dilated-conv products of the current one -- so that at most the 8 running tasks and a few taken
         // ones are unfinished at any time: the tiles a taken task depends on lie 15..19 tasks back and have long finished.
+        // (a.tune bits 13..16, probe: wave k starts k x that many s_sleep(4) = 256-cycle units late -- an even stagger of the eight
+        // waves puts a task's dependencies 7/8 of a task time behind it and the two waves of a SIMD half a task apart)
+        for (int s = wave * ((a.tune >> 13) & 15); s > 0; --s) __builtin_amdgcn_s_sleep(4);
         int n = wave, blk = (n * m_units) >> 16, u = n - blk * units;  // this wave's current task
         int pend_u = -1, pend_v = 0;                                   // a finished task whose flag is not published yet
         Ops cur;

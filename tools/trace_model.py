@@ -58,6 +58,11 @@ print("per-task segment cycles (median / mean / p90), %d tasks, fetched ahead %.
 for i, nm in enumerate(names):
     print("  %-45s %6.0f %6.0f %6.0f" % (nm, np.median(d[:, i]), d[:, i].mean(), np.percentile(d[:, i], 90)))
 print("  task total                                    %6.0f %6.0f" % (np.median(st[:, 5] - st[:, 0]), (st[:, 5] - st[:, 0]).mean()))
+nd = 6  # dilations per stack
+for dcl in range(nd):
+    k = ((np.arange(len(r)) // units) % nd) == dcl
+    print("  blocks of dilation %2d: fetched ahead %5.1f %%, task total median %5.0f, next-operands segment median %5.0f" % (
+        1 << dcl, 100.0 * fe[k].mean(), np.median((st[:, 5] - st[:, 0])[k]), np.median(d[k, 3])))
 for w in range(8):
     k = np.where(wv == w)[0]
     gaps = st[k[1:], 0] - st[k[:-1], 5]
