@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsmh.so")
+# (SMH_LIBSMH_PATH: another build of the same library, for A/B timing of two kernel versions on one box -- tools only)
+LIB_PATH = os.environ.get("SMH_LIBSMH_PATH") or os.path.join(HERE, "libsmh.so")
 
 SMH_OK, SMH_E_INVALID, SMH_E_HIP, SMH_E_WORKSPACE, SMH_E_DEVICE = 0, -1, -2, -3, -4
 

@@ -579,7 +579,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         // (an LDS-typed pointer: a generic volatile access would be a flat load that waits for the weight loads in flight)
         typedef __attribute__((address_space(3))) volatile int lds_vint;
         // [0..31] per tile, [56..59] (kSkew16) the block whose weights have landed in ring slot 0..3, [62] the task counter,
-        // [63] = a wave gave up waiting
+        // [63] = a wave gave up waiting, [64..127] per-lane scratch words (targets of the lanes that have nothing to say)
         lds_vint *done = (lds_vint *)(flagbase);
         if (threadIdx.x < 64) {
             int v = threadIdx.x == 62 ? nw : 0;
@@ -641,14 +641,10 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             const int base = 16 * u, R = base + j;
             int g = (int)__umulhi((unsigned)base, m_T);  // patch of the tile's first row (only the training build uses g)
             int t = base - T * g + j;                    // frame index of row R inside its patch
-            if (T >= 16) {
+            {   // (T >= 16 -- launch_forward takes this schedule only then --: a 16-row tile crosses at most one patch boundary;
+                // the loop that shorter patches needed was two branches in every task's operand fetch)
                 const bool wr = t >= T;
                 t -= wr ? T : 0, g += wr ? 1 : 0;
-            } else {
-                while (__any(t >= T)) {
-                    const bool wr = t >= T;
-                    t -= wr ? T : 0, g += wr ? 1 : 0;
-                }
             }
             const bool past = R >= GR;  // rows behind the last patch repeat its last row (frame T - 1)
             const int Rc = past ? GR - 1 : R;
@@ -682,7 +678,7 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         auto dep_mask = [&](int blk, int u) {
             // (a dilation >= T reaches nothing: its side taps lie in the zero padding of every row, see issue_ops)
             const int dr = dil(blk), dw = dil(blk > 0 ? blk - 1 : 0);
-            const int dmax = (a.tune & 4) ? max(dr, dw) : max(dr < T ? dr : 0, dw < T ? dw : 0);
+            const int dmax = max(dr < T ? dr : 0, dw < T ? dw : 0);
             const int w = min((dmax + 15) >> 4, 31);
             const unsigned long long win = ((2ull << (2 * w)) - 1ull) << u;  // 2 w + 1 ones from bit u
             return (unsigned)(win >> w) & all_tiles;                         // ... centred on u
@@ -725,13 +721,16 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
             if (blk > 0) wait_for(blk, u);  // fewer tiles than waves: a wave's first task may sit in a later block (kSkew16: + its weights)
             issue_ops(cur, blk, u);
         }
+        // Branch-free on purpose (as is the task counter below): a lane-0-only LDS access compiles to an exec save, a skip branch and
+        // an exec restore, and every branch ends a scheduling region of the task body -- two uniform branches more per task cost
+        // this kernel 3 % (round 3).  All 64 lanes store; lane 0 hits the flag, lane l > 0 (and lane 0 when nothing is pending)
+        // a scratch word of its own behind the flags: done[64 + l].
         auto publish = [&]() {
-            if (pend_u >= 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the finished task's rows are in LDS before its flag moves
-                // (a.tune & 256, test_skew_give_up_is_reported only: wave 1 never publishes -- its dependants must give up)
-                if (lane == 0 && !((a.tune & 256) && wave == 1)) done[pend_u] = pend_v;
-                pend_u = -1;
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the finished task's rows are in LDS before its flag moves
+            // (a.tune & 256, test_skew_give_up_is_reported only: wave 1 never publishes -- its dependants must give up)
+            const bool real = lane == 0 && pend_u >= 0 && !((a.tune & 256) && wave == 1);
+            done[real ? pend_u : 64 + lane] = pend_v;
+            pend_u = -1;
         };
         // (kSkew16) a block this wave has put on its way into the ring (stage_ring, below) and not yet named in its slot's flag word
         int staged = -1;
@@ -779,8 +778,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 publish_staged();
                 // take the next task and sample the flags; both are judged behind the epilogue
                 if (stamp) st[2] = __builtin_amdgcn_s_memtime();
-                int taken = 0;
-                if (lane == 0) taken = __hip_atomic_fetch_add((int *)(done + 62), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (lane 0 counts on the task counter, every other lane on its scratch word: one ds_add_rtn, no exec branch)
+                const int taken = __hip_atomic_fetch_add((int *)(done + (lane == 0 ? 62 : 64 + lane)), 1, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int have = done[lane];
                 // relu + channel-max normalisation ('norm_relu'); 1 / (max + eps) by v_rcp_f32 (1 ulp)
                 float mx = 0.f;
@@ -810,7 +810,9 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                 const bool have_next = nn < n_tasks;
                 const int nnc = min(nn, n_tasks - 1);
                 const int nblk = (nnc * m_units) >> 16, nu = nnc - nblk * units;
-                const bool fetched = have_next && (nblk == 0 || stands(have, nblk, dep_mask(nblk, nu))) && w_ready(have, nblk);
+                // (no short circuits: every flag word is >= 0, so block 0 stands by itself, and three scalar ANDs cost less than the
+                // branches a chain of && / || compiles to -- the task body should stay one scheduling region)
+                const bool fetched = (int)have_next & (int)stands(have, nblk, dep_mask(nblk, nu)) & (int)w_ready(have, nblk);
                 issue_ops(cur, nblk, nu);
                 if (stamp) st[4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -1194,7 +1196,7 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     // full rounds of the 8 waves: 162 / 154).  SMH_TCN_SKEW=0 / 2: never / whenever it can run (tests, tuning).
     // (the schedule decodes task n into (block, tile) by multiplication, exact for n < 2048: smh_model_create accepts up to
     // nb_stacks x 16 dilations, the reference tunes nb_stacks up to 10 -- beyond the bound the barrier schedule runs)
-    const bool skew_ok = a.wlds && units <= 32 && units >= 1 && a.n_blocks * units < 2048;
+    const bool skew_ok = a.wlds && units <= 32 && units >= 1 && a.n_blocks * units < 2048 && a.T >= 16;  // (T >= 16: issue_ops)
     // (13 tiles: since the lone last-round tile is shared by two waves the barrier schedule is ahead there -- W = 68 x 768 patches
     // 130.1 against 131.5 us, W = 99 x 510 131.5 / 134.7; at 17 tiles the skew schedule stays ahead, 149.8 / 157.5)
     bool skew = skew_ok && units >= 12 && 8 * ((units + 7) / 8) - units >= 3 && units != 13;
@@ -1206,7 +1208,7 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     // 8-wave form (tools/gpu/r3_net.sh) -- twice the waves per SIMD buy nothing, i.e. the loop is not short of waves to hide
     // latency behind: exact-f32 MFMA and the VALU work of the epilogues do not overlap.  Kept as the measured
     // experiment and as a third implementation the schedule-agreement test holds bit-identical to the other two.
-    const size_t lds16 = sizeof(float) * (2 * (size_t)(a.GRP + 1) * SX + (size_t)kWeightRing * kBlockFloats + 64);
+    const size_t lds16 = sizeof(float) * (2 * (size_t)(a.GRP + 1) * SX + (size_t)kWeightRing * kBlockFloats + 128);  // + flags and scratch words
     bool skew16 = false;
     if (const char *ev = getenv("SMH_TCN_SKEW16")) skew16 = atoi(ev) != 0 && skew && !tio && !a.trace && lds16 <= 156 * 1024;
     if (skew16) nwaves = 16, lds = lds16;
