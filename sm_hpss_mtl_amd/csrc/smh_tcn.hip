@@ -713,6 +713,16 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
         // (a.tune bits 13..16, probe: wave k starts k x that many s_sleep(4) = 256-cycle units late -- an even stagger of the eight
         // waves puts a task's dependencies 7/8 of a task time behind it and the two waves of a SIMD half a task apart)
         for (int s = wave * ((a.tune >> 13) & 15); s > 0; --s) __builtin_amdgcn_s_sleep(4);
+        // (a.tune bits 17..18, probe: a static priority for the younger wave of every SIMD -- arbitration by age lets the older one
+        // complete 55-57 tasks to the younger's 45-47; set once, outside the task loop)
+        if (wave >= 4) {
+            switch ((a.tune >> 17) & 3) {
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                default: break;
+            }
+        }
         int n = wave, blk = (n * m_units) >> 16, u = n - blk * units;  // this wave's current task
         int pend_u = -1, pend_v = 0;                                   // a finished task whose flag is not published yet
         Ops cur;
