@@ -313,6 +313,7 @@ struct FeatPlan {
 };
 constexpr int kWalkBatch = 8;  // bins of loads in flight per lane
 constexpr int kHalfBatch = 8;   // the same in features_half_kernel (lane = frame pair)
+constexpr int kL0Steps = 30;    // k steps of the layer-0 products (four rows each) that features_half_kernel's per-M-tile form is built for: 120 mel rows
 
 __global__ void __launch_bounds__(1024)
 hp_feat_walk_kernel(FeatPlan fp, int log_db, const float *__restrict__ S, const float *__restrict__ harm,
@@ -1065,8 +1066,58 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             }
         }
     };
+    // The same products with ONE TASK PER (16-frame tile, 16-channel M-tile), for the reference's 120 mel rows (kL0Steps k steps) and
+    // the weights in L2.  Waves 2 i and 2 i + 1 take the two M-tiles of tiles i, i + nw/2, ...: they read the same standardised
+    // values (the B operand), each multiplies its own 16 output channels, and a wave keeps ITS M-tile's weights of every k step in
+    // 30 registers for all its tiles -- requested in one batch, one L2 round trip per wave, where the task above runs a chain of
+    // four [16 loads -> wait -> 16 products] groups.  Per M-tile the sums are the ones of the undivided task -- even k steps on one
+    // accumulator chain, odd steps on a second, added at the end -- so x0p keeps its bits.  (Requesting the weights in front of the
+    // statistics phase, to hide that round trip as well, takes the kernel from 79 to 109 VGPRs: one workgroup less per CU.)
+    auto layer0_mtile = [&](const float *wu) {
+        const int q = lane >> 4, j = lane & 15, mt = wave & 1;
+        const int ut = (W + 15) >> 4;
+        float wa[kL0Steps];
+        {
+            const float *wl = wu + (q * 32 + j + 16 * mt);
+#pragma unroll
+            for (int s = 0; s < kL0Steps; ++s) wa[s] = wl[s * 128];
+        }
+        const float *mq = s_mean + q, *lq = s_lo + q, *iq = s_inv + q;
+        for (int pu = wave >> 1; pu < nP * ut; pu += nw >> 1) {
+            // (the statistics are the same for every tile: without this fence the compiler keeps all 90 of them in registers)
+            asm volatile("" ::: "memory");
+            const int p = pu / ut, u = pu - p * ut;
+            int s = p * shift;
+            const int e = min(s + W, Ttiled);
+            if (e - s < W) s = e - W;
+            const int jt = 16 * u + j;
+            int tt = s + min(jt, W - 1);
+            tt -= (tt / T) * T;
+            const float *tl = img + tt + q * ld;
+            f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca;
+#pragma unroll
+            for (int s0 = 0; s0 < kL0Steps; s0 += 6) {
+                float xs[6], is[6], hs[6], ls[6];
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    xs[g] = tl[(s0 + g) * 4 * ld];
+                    hs[g] = mq[(s0 + g) * 4], ls[g] = lq[(s0 + g) * 4], is[g] = iq[(s0 + g) * 4];
+                }
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    const float c = __fsub_rn(__fsub_rn(xs[g], hs[g]), ls[g]) * is[g];
+                    if ((s0 + g) & 1) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s0 + g], c, cb, 0, 0, 0);
+                    else ca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s0 + g], c, ca, 0, 0, 0);
+                }
+            }
+            ca += cb;
+            if (jt < W)
+                *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q + 16 * mt) = ca;
+        }
+    };
     if (x0p) {
         if (w0_lds) layer0(w0s);
+        else if (rows == 4 * kL0Steps && !(nw & 1)) layer0_mtile(w0 + (size_t)half * rows * 32);
         else layer0(w0 + (size_t)half * rows * 32);  // weights straight from L2: 15 KB less LDS, three workgroups per CU
     }
     stamp(5);  // layer 0
