@@ -980,7 +980,14 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             img[r * ld + 2 * t2] = x0;
             img[r * ld + 2 * t2 + 1] = x1;
             f32x2 v = {x0, x1};
+            // nontemporal on purpose (tools/gpu/r3_feat_nt.sh): as plain stores the rows merge into whole lines in L2 (WRITE_SIZE 121.7 ->
+            // 114.2 MB per 1024 clips, the bytes of fv + x0p) but push out the S / harm / perc lines the other half's workgroup is
+            // about to read (FETCH_SIZE 309 -> 321 MB) and the kernel takes 118.3 us instead of 111.7
+#ifdef SMH_PLAIN_FV_STORES  // (A/B build only)
+            reinterpret_cast<f32x2 *>(g + (size_t)r * T)[t2] = v;
+#else
             __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(g + (size_t)r * T) + t2);
+#endif
         }
     }
     stamp(2);  // dB + clip + write

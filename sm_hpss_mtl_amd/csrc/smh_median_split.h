@@ -121,8 +121,16 @@ __device__ __forceinline__ void split_median_walk(const float *line, int es_rt, 
     auto emit = [&](int j, float v, bool guard) {
         if (!guard || j < n_out) {
             float *dst = reinterpret_cast<float *>(obase + off);
+            // Plain stores also for the percussive rows (kStridedStream): a wave's 256-byte piece of a 392-byte row shares its
+            // first and last line with the neighbouring pieces, which arrive a bin step later from this or another wave of the
+            // workgroup -- in L2 they merge into whole lines; as nontemporal stores the partial lines left for HBM at once
+            // (WRITE_SIZE 184 MB per 1024 clips against 160 MB now = the bytes of harm + perc; tools/gpu/r3_median_nt.sh).
+#ifdef SMH_NT_STORES  // (A/B build only)
             if constexpr (STORE == kStridedStream) __builtin_nontemporal_store(v, dst);
             else *dst = v;
+#else
+            *dst = v;
+#endif
         }
         off += ostep;
     };

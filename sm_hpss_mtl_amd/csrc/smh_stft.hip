@@ -350,7 +350,8 @@ __device__ __forceinline__ void dft25(float2 *x) {
 template <int ROW>  // float2 pitch of a phase-1 table row: 25, or 40 = the 25 entries and the first 15 again (below)
 __global__ void __launch_bounds__(512, 4)
 stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window, const float2 *__restrict__ twM,
-               const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe) {
+               const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe, int B,
+               int ntiles) {
     // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
     constexpr int M = 200, K = 201;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -360,7 +361,18 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     v2 *Z = win2 + 8 * ROW;   // F frames of kMP400
     // (ROW == 40) table column of item `it` (= 25 f + n2): n2, + 25 behind a frame change inside the item's 16-lane group
     auto column = [&](int it, int f, int n2) { return ROW == 25 ? n2 : n2 + 25 * (f - (it & ~15) / 25); };
-    const int b = blockIdx.y, t0 = blockIdx.x * F, tid = threadIdx.x;
+    // Workgroup -> (clip, frame tile).  ntiles > 0: a 1-D grid decoded so that the tiles of one clip run on ONE XCD, dispatched next
+    // to each other (workgroup i goes to XCD i % 8): a row of S is 98 frames = 392 bytes and a tile writes an 80-byte piece of it,
+    // so the lines of a row are completed by up to three tiles -- in one L2 they merge before they leave for HBM (with the tiles
+    // of a clip spread over five XCDs every piece left as a partial line: WRITE_SIZE 105 MB for 80.7 MB of S), and the 240 samples
+    // neighbouring tiles share are fetched once.  ntiles == 0: the plain (tile, clip) grid.
+    int b = blockIdx.y, tile = blockIdx.x;
+    if (ntiles > 0) {
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        b = (jj / ntiles) * 8 + xcd, tile = jj % ntiles;
+        if (b >= B) return;
+    }
+    const int t0 = tile * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
     const int nthr = blockDim.x;
     const float *clip = audio + (size_t)b * n_samples + (size_t)t0 * hop;
@@ -511,10 +523,13 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         const size_t lds = sizeof(float2) * (8 * row + 202 + 8 * row + (size_t)F * kMP400);
         auto kernel = row == 40 ? stft400_kernel<40> : stft400_kernel<25>;
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((T + F - 1) / F, B), block(nthreads);
+        const int nt = (T + F - 1) / F;
+        const bool by_xcd = getenv("SMH_STFT_XCD") == nullptr || atoi(getenv("SMH_STFT_XCD")) != 0;  // SMH_STFT_XCD=0: the plain grid (A/B)
+        dim3 grid(nt, B), block(nthreads);
+        if (by_xcd) grid = dim3((unsigned)nt * 8u * (unsigned)((B + 7) / 8), 1);
         const int probe = smh::probe_env("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
-                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe);
+                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe, B, by_xcd ? nt : 0);
         return smh::launch_status("stft400_kernel");
     }
     StftArgs a;
