@@ -825,14 +825,8 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // blocks i and i + 8 share an XCD (round-robin dispatch): clip 8 g + r, half h  <->  block 16 g + 8 h + r
-    int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
-    int half = rr >> 3, b = grp * 8 + (rr & 7);
-    if (const int pn = (stop_after >> 16) & 255; pn > 1) {
-        // (experiment SMH_FEAT_PAIR_N = n) an XCD's sequence is n harmonic halves, then the n percussive halves of the same clips:
-        // the second reader of a clip's S / harm / perc starts n dispatch slots behind the first instead of right behind it
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, g2 = j / (2 * pn), wi = j - g2 * 2 * pn;
-        half = wi / pn, b = (g2 * pn + (wi - half * pn)) * 8 + xcd;
-    }
+    const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
+    const int half = rr >> 3, b = grp * 8 + (rr & 7);
     if (b >= B) return;
     const bool w0_lds = !(stop_after & 16);  // bit 4 of the probe argument: layer-0 weights from L2 instead of an LDS copy
     // bits 8..15 (timing probe SMH_FEAT_PROBE_PERC = n, outputs invalid): what "the percussive median inside this walk" would
@@ -1264,16 +1258,11 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         // needs 49 KB and THREE share a CU (77 VGPRs: 6 waves per SIMD) -- 127-130 -> 113-115 us; SMH_FEAT_W0LDS=1: the copy
         const bool w0_l2 = getenv("SMH_FEAT_W0LDS") == nullptr;
         if (x0p && !w0_l2) ldh += sizeof(float) * rows * 32;
-        int probe = (stop & ~16) | (w0_l2 ? 16 : 0);
-        unsigned grid = 16u * (unsigned)((B + 7) / 8);
-        if (const char *ev = getenv("SMH_FEAT_PAIR_N")) {  // experiment: spacing of a clip's two halves in an XCD's dispatch order
-            const int pn = std::max(1, std::min(atoi(ev), 255));
-            if (pn > 1) {
-                probe |= pn << 16;
-                const unsigned per_xcd = (unsigned)((B + 7) / 8);
-                grid = 16u * ((per_xcd + pn - 1) / pn) * pn;
-            }
-        }
+        const int probe = (stop & ~16) | (w0_l2 ? 16 : 0);
+        // (the two halves of a clip back to back in their XCD's dispatch order: consecutive workgroups land on the same CU and the
+        // second finds the first one's S / harm / perc lines in that CU's vector cache -- n halves apart the kernel takes 134 us
+        // instead of 111, profiles/r03_store_policies.txt)
+        const unsigned grid = 16u * (unsigned)((B + 7) / 8);
         if (getenv("SMH_FEAT_OCC")) {  // tools only: what the runtime says about residency
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)features_half_kernel<2, false>, 512, ldh);
