@@ -29,6 +29,7 @@ struct StftArgs {
     float inv_ns[smh::kMaxFftStages];  // 1 / Ns of the stage
     int tmul[smh::kMaxFftStages];      // M / (Ns * radix)
     float inv_tt;
+    int B, xcd_tiles;  // xcd_tiles > 0: 1-D grid, neighbouring tiles on one XCD (see stft400_kernel); the value is the tiles per clip
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -169,8 +170,14 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
     float2 *tw2 = lds + M;      // M + 1 untangle twiddles
     float2 *buf0 = tw2 + (M + 1);
     float2 *buf1 = buf0 + a.tt * MP;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * a.tt;
+    int b = blockIdx.y, tile = blockIdx.x;
+    if (a.xcd_tiles > 0) {  // the (clip, tile) items in 8 contiguous ranges, one per XCD: stft400_kernel has the reasoning
+        const unsigned total = (unsigned)a.B * (unsigned)a.xcd_tiles, per_xcd = (total + 7u) >> 3;
+        const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
+        if (j >= per_xcd || n >= total) return;
+        b = (int)(n / (unsigned)a.xcd_tiles), tile = (int)(n - (unsigned)b * (unsigned)a.xcd_tiles);
+    }
+    const int t0 = tile * a.tt;
     const int nf = min(a.tt, a.T - t0);
     for (int i = threadIdx.x; i < M; i += blockDim.x) tw[i] = twM[i];
     for (int i = threadIdx.x; i <= M; i += blockDim.x) tw2[i] = tw2M[i];
@@ -361,16 +368,19 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     v2 *Z = win2 + 8 * ROW;   // F frames of kMP400
     // (ROW == 40) table column of item `it` (= 25 f + n2): n2, + 25 behind a frame change inside the item's 16-lane group
     auto column = [&](int it, int f, int n2) { return ROW == 25 ? n2 : n2 + 25 * (f - (it & ~15) / 25); };
-    // Workgroup -> (clip, frame tile).  ntiles > 0: a 1-D grid decoded so that the tiles of one clip run on ONE XCD, dispatched next
-    // to each other (workgroup i goes to XCD i % 8): a row of S is 98 frames = 392 bytes and a tile writes an 80-byte piece of it,
-    // so the lines of a row are completed by up to three tiles -- in one L2 they merge before they leave for HBM (with the tiles
-    // of a clip spread over five XCDs every piece left as a partial line: WRITE_SIZE 105 MB for 80.7 MB of S), and the 240 samples
-    // neighbouring tiles share are fetched once.  ntiles == 0: the plain (tile, clip) grid.
+    // Workgroup -> (clip, frame tile).  ntiles > 0: a 1-D grid decoded so that NEIGHBOURING TILES RUN ON ONE XCD, dispatched next to
+    // each other.  A row of S is T frames (98: 392 bytes) and a tile writes an 80-byte piece of it, so the lines of a row are completed
+    // by up to three tiles -- in one L2 they merge before they leave for HBM; with consecutive tiles on consecutive XCDs (the plain
+    // grid: workgroup i goes to XCD i % 8) every piece left as a partial line (WRITE_SIZE 105 MB for 80.7 MB of S), and the 240 samples
+    // neighbouring tiles share were fetched twice.  The (clip, tile) items in clip-major order are cut into 8 contiguous ranges, one
+    // per XCD: the same rule serves a batch of a thousand clips (an XCD owns 128 whole clips) and a single long file (an XCD owns an
+    // eighth of its tiles).  ntiles == 0: the plain (tile, clip) grid.
     int b = blockIdx.y, tile = blockIdx.x;
     if (ntiles > 0) {
-        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-        b = (jj / ntiles) * 8 + xcd, tile = jj % ntiles;
-        if (b >= B) return;
+        const unsigned total = (unsigned)B * (unsigned)ntiles, per_xcd = (total + 7u) >> 3;  // (the launch keeps B * ntiles below 2^31)
+        const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
+        if (j >= per_xcd || n >= total) return;
+        b = (int)(n / (unsigned)ntiles), tile = (int)(n - (unsigned)b * (unsigned)ntiles);
     }
     const int t0 = tile * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
@@ -524,9 +534,11 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         auto kernel = row == 40 ? stft400_kernel<40> : stft400_kernel<25>;
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nt = (T + F - 1) / F;
-        const bool by_xcd = getenv("SMH_STFT_XCD") == nullptr || atoi(getenv("SMH_STFT_XCD")) != 0;  // SMH_STFT_XCD=0: the plain grid (A/B)
+        bool by_xcd = true;  // SMH_STFT_XCD=0: the plain (tile, clip) grid (A/B, tests)
+        if (const char *ev = getenv("SMH_STFT_XCD")) by_xcd = atoi(ev) != 0;
+        if ((long long)B * nt >= (1ll << 31) - 8) by_xcd = false;
         dim3 grid(nt, B), block(nthreads);
-        if (by_xcd) grid = dim3((unsigned)nt * 8u * (unsigned)((B + 7) / 8), 1);
+        if (by_xcd) grid = dim3((unsigned)(8 * (((long long)B * nt + 7) / 8)), 1);
         const int probe = smh::probe_env("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
                            ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe, B, by_xcd ? nt : 0);
@@ -556,7 +568,12 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
     SMH_REQUIRE((size_t)a.tt * a.K < (1u << 20), "smh_stft_mag_f32: tile too large");
     SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft_mag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    dim3 grid((T + a.tt - 1) / a.tt, B), block(kThreads);
+    const int ntg = (T + a.tt - 1) / a.tt;
+    bool xcd_grid = (long long)B * ntg < (1ll << 31) - 8;
+    if (const char *ev = getenv("SMH_STFT_XCD")) xcd_grid = xcd_grid && atoi(ev) != 0;
+    a.B = B, a.xcd_tiles = xcd_grid ? ntg : 0;
+    dim3 grid(ntg, B), block(kThreads);
+    if (xcd_grid) grid = dim3((unsigned)(8 * (((long long)B * ntg + 7) / 8)), 1);
     hipLaunchKernelGGL(stft_mag_kernel, grid, block, lds, (hipStream_t)stream, a, d_audio, ctx->d_window, ctx->d_twM,
                        ctx->d_tw2M, d_S);
     return smh::launch_status("stft_mag_kernel");

@@ -38,17 +38,18 @@ def test_stft_mag_vs_oracle(fe, clips4, golden_fe):
     assert np.max(np.abs(S[0] - golden_fe["S"])) <= 1e-5 * golden_fe["S"].max()
 
 
-@pytest.mark.parametrize("B", [1, 3, 8, 9, 21])
-def test_stft_xcd_grid_equals_plain_grid_at_any_batch(B, monkeypatch):
-    """The 1-D grid that keeps the frame tiles of a clip on one XCD (csrc/smh_stft.hip) decodes (clip, tile) from the workgroup index:
-    batch sizes that are not multiples of 8 leave workgroups without a clip.  Same bits as the plain (tile, clip) grid, every clip
-    within 1e-5 max|S| of the oracle, and nothing written behind the batch."""
+@pytest.mark.parametrize("n_fft", [400, 512])
+@pytest.mark.parametrize("B", [1, 3, 8, 9, 21, 67])
+def test_stft_xcd_grid_equals_plain_grid_at_any_batch(B, n_fft, monkeypatch):
+    """The 1-D grid that keeps neighbouring frame tiles on one XCD (csrc/smh_stft.hip) decodes (clip, tile) from the workgroup index:
+    the (clip, tile) items are cut into 8 contiguous ranges, and item counts that are not multiples of 8 leave workgroups without an
+    item.  Same bits as the plain (tile, clip) grid, every clip within 1e-5 max|S| of the oracle, nothing written behind the batch."""
     import ctypes as C
     from sm_hpss_mtl_amd import _lib
     from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
     from sm_hpss_mtl_amd.synth import synth_clips
-    y = synth_clips(B, seed=77)[:, :7000 + 160 * (B % 5)]  # 40-44 frames: 2-3 tiles, the last one short
-    f = Frontend(FrontendConfig())
+    y = synth_clips(B, seed=77)[:, :7000 + 160 * (B % 5)]  # 40-44 frames: 2-4 tiles, the last one short
+    f = Frontend(FrontendConfig() if n_fft == 400 else FrontendConfig(n_fft=512, win_length=400, n_mels=0, log_db=True))  # 512: the generic kernel
     T = f.num_frames(y.shape[1])
     buf = torch.full((B + 1, f.K, T), -7.0, device="cuda")  # one guard clip behind the batch
     lib, st = f.lib, C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -59,6 +60,7 @@ def test_stft_xcd_grid_equals_plain_grid_at_any_batch(B, monkeypatch):
         _lib.check(lib.smh_stft_mag_f32(f._h, C.c_void_p(ya.data_ptr()), B, y.shape[1], C.c_void_p(buf.data_ptr()), st))
         return buf.clone()
 
+    monkeypatch.setenv("SMH_STFT_XCD", "1")
     got = run()
     monkeypatch.setenv("SMH_STFT_XCD", "0")
     plain = run()
@@ -66,7 +68,7 @@ def test_stft_xcd_grid_equals_plain_grid_at_any_batch(B, monkeypatch):
     assert bool((got[B] == -7.0).all())
     Sh = host(got[:B])
     for i in range(B):
-        ref = ofe.stft_mag(y[i])
+        ref = ofe.stft_mag(y[i]) if n_fft == 400 else ofe.stft_mag(y[i], n_fft=512, win_length=400, hop=160)
         assert Sh[i].shape == ref.shape and np.max(np.abs(Sh[i] - ref)) <= 1e-5 * ref.max()
 
 
