@@ -261,6 +261,18 @@ int smh_features_l0_f32(const smh_ctx *ctx, const float *d_S, const float *d_har
                         int B, int T, int W, int shift, float *d_fv, float *d_patches, const float *d_w0, float *d_x0p,
                         int32_t *d_maxkeys, void *stream);
 int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk, void *stream);
+/* Dense file-level inference: the per-batch body of `patch_probability_generator`,
+ * DAFx12_Speech_Music_Detection_B3_MTL_v2.py:634-665 -- every hop-`shift` patch of a 10 000-frame batch of one file's featuregram
+ * through model.predict.  d_fv (n_feat, Tc) float32: the batch as get_feature_patches leaves it in front of the patch extraction
+ * (each half standardised over the batch, lib/preprocessing.py:208-224); patch p = frames [min(p*shift, Tc - W), + W), p <
+ * smh_num_patches(Tc, W, shift) -- tools.extract_patches' grid (tools.pyx:24-34).  Returns the number of patches (>= 0) or an error;
+ * d_out (nP, out_dim) as smh_model_forward_f32 writes it, to the same f32 tolerance.  Nothing of size nP x W x n_feat is built: the
+ * first layer (a 1x1 convolution) is evaluated once per FRAME into d_work ((2, Tc, 32) float32 =
+ * smh_model_dense_workspace_bytes) and every patch is read as a window of it.  Needs Tc >= W (shorter batches are tiled by
+ * get_feature_patches: build the patches and call smh_model_forward_f32), n_feat a multiple of 8, block_variant 0. */
+size_t smh_model_dense_workspace_bytes(const smh_model *m, int Tc);
+int smh_model_forward_dense_f32(const smh_model *m, const float *d_fv, int Tc, int shift, void *d_work, size_t work_bytes,
+                                float *d_out, void *stream);
 /* Same forward with bf16 matrix-core operands and f32 accumulation / residual stream / normalisation (BASELINE config 5,
  * "mixed bf16 CNN + fp32 HPSS").  Weights are split once per weight version, activations right before each product.
  *   split = 1 (what smh_model_forward_bf16 runs): every operand is hi + lo (two bf16 values, 16 mantissa bits), every

@@ -29,6 +29,8 @@ struct TcnArgs {
     int spin_limit;  // polls before a wave of the skewed schedule gives up (kSkewSpinLimit; lowered only by the debug knob of the test)
     int split_last;  // barrier schedule, two register sets: the last column tile is computed by TWO waves, 16 output channels each (smh_tcn.hip: half_tile_compute)
     int from_x0;  // X holds the two per-half partials of layer 0, (N, 2, T, 32) (smh_features_l0_f32), instead of patches
+    int x0_shift, x0_T;  // from_x0 with x0_shift > 0 (smh_model_forward_dense_f32): X is (2, x0_T, 32), the partials of EVERY frame of a
+                         // featuregram of x0_T frames; patch n is the window of T frames starting at min(n * x0_shift, x0_T - T)
     int head_odim[kMaxHeads];
     int head_sigmoid[kMaxHeads];
 };
@@ -94,7 +96,7 @@ Offsets offsets(const smh_model *m);
 void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
 int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
-                   hipStream_t st, int from_x0 = 0);
+                   hipStream_t st, int from_x0 = 0, int x0_shift = 0, int x0_T = 0);
 // smh_model_cfg.block_variant = 1 (smh_tcn_v2.hip): the two-convolution residual block of keras-tcn >= 2.8, inference only
 int launch_forward_v2(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, hipStream_t st);
 }  // namespace smh_tcn

@@ -427,9 +427,11 @@ b3mtl_forward_kernel(TcnArgs a, const float *__restrict__ X, const float *__rest
                     const int i = min(i0 + r * (int)blockDim.x, n4 - 1);
                     const int R = i >> 3, c4 = (i & 7) * 4;
                     const int g = R / T, t = R - g * T;
-                    const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + t) * C + c4);
+                    // packed partials (n, 2, T, 32), or windows of the per-frame partials (2, x0_T, 32) of a whole featuregram
+                    const size_t first = a.x0_shift ? (size_t)min((n0 + g) * a.x0_shift, a.x0_T - T) : (size_t)(n0 + g) * 2 * T;
+                    const float *p0 = X + ((first + t) * C + c4);
                     pa[r] = *reinterpret_cast<const f32x4 *>(p0);
-                    pb[r] = *reinterpret_cast<const f32x4 *>(p0 + (size_t)T * C);
+                    pb[r] = *reinterpret_cast<const f32x4 *>(p0 + (size_t)(a.x0_shift ? a.x0_T : T) * C);
                 }
 #pragma unroll
                 for (int r = 0; r < kX0R; ++r) {
@@ -1139,7 +1141,7 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
     a.skip_heads = 0;
     a.tune = 0;
     a.trace = nullptr;
-    a.from_x0 = 0;
+    a.from_x0 = 0, a.x0_shift = 0, a.x0_T = 0;
     a.status = m->d_status, a.spin_limit = kSkewSpinLimit;
     a.D = m->D, a.NH = m->NH, a.n_mt = m->n_mt, a.n_classes = m->cfg.n_classes, a.n_heads = m->n_heads;
     a.out_dim = m->out_dim;
@@ -1173,11 +1175,11 @@ void fill_args(const smh_model *m, int N, TcnArgs *pa, size_t *plds) {
 }
 
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
-                   hipStream_t st, int from_x0) {
+                   hipStream_t st, int from_x0, int x0_shift, int x0_T) {
     TcnArgs a;
     size_t lds;
     fill_args(m, N, &a, &lds);
-    a.from_x0 = from_x0;
+    a.from_x0 = from_x0, a.x0_shift = x0_shift, a.x0_T = x0_T;
     // timing probes (outputs invalid; training would read stale activations): only under SMH_ENABLE_PROBES=1, announced on stderr
     if (const char *ev = smh::probe_env("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // tools/tune_model.py
     a.skip_heads = smh::probe_env("SMH_TCN_NOHEADS") ? 1 : 0;
@@ -1374,6 +1376,66 @@ extern "C" int smh_model_get_weights(const smh_model *m, float *h, size_t n, voi
 
 extern "C" const float *smh_model_w0_ptr(const smh_model *m) {
     return (m && m->cfg.block_variant == 0) ? m->d_flat + smh_tcn::offsets(m).w0_k : nullptr;
+}
+
+// ---- dense file-level inference (DAFx12_Speech_Music_Detection_B3_MTL_v2.py:634-665): every hop-`shift` patch of a
+// standardised featuregram chunk.  The network's first layer is a 1x1 convolution -- pointwise in time -- and the chunk is standardised
+// as a whole, so a frame has the same layer-0 output in every patch that contains it: l0_frames_kernel computes it ONCE per frame (as
+// the two per-half partial sums the forward's from_x0 entry adds up) and the forward kernel reads each patch as a window of that
+// (2, Tc, 32) array.  Per 10 000-frame chunk at hop 1 that replaces 648 MB of materialised (9 932, 68, 240) patches, read back by
+// layer 0, by 2.6 MB.
+namespace {
+// one wave per (16-frame tile, half): D[c][t] = sum_r W0[half * rows + r][c] * fv[half * rows + r][t], both 16-channel M-tiles;
+// k order and the two accumulator chains per M-tile as in the feature kernel's layer-0 phase (smh_feat.hip)
+__global__ void __launch_bounds__(256)
+l0_frames_kernel(const float *__restrict__ fv, const float *__restrict__ w0, float *__restrict__ x0, int rows, int Tc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const int tile = blockIdx.x * 4 + wave, half = blockIdx.y;
+    if (tile * 16 >= Tc) return;
+    const int t = min(tile * 16 + j, Tc - 1);
+    const float *xr = fv + ((size_t)half * rows + q) * Tc + t;
+    const float *wr = w0 + ((size_t)half * rows + q) * 32 + j;
+    f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = c0a, c1a = c0a, c1b = c0a;
+    const int nst = rows >> 2;
+    for (int s0 = 0; s0 < nst; s0 += 2) {
+        const int s1 = min(s0 + 1, nst - 1);
+        const float xa = xr[(size_t)4 * s0 * Tc], xb = s0 + 1 < nst ? xr[(size_t)4 * s1 * Tc] : 0.f;
+        const float wa0 = wr[4 * s0 * 32], wa1 = wr[4 * s0 * 32 + 16], wb0 = wr[4 * s1 * 32], wb1 = wr[4 * s1 * 32 + 16];
+        c0a = mfma4(wa0, xa, c0a), c1a = mfma4(wa1, xa, c1a);
+        c0b = mfma4(wb0, xb, c0b), c1b = mfma4(wb1, xb, c1b);
+    }
+    c0a += c0b, c1a += c1b;
+    if (tile * 16 + j < Tc) {
+        float *o = x0 + (((size_t)half * Tc + tile * 16 + j) * 32 + 4 * q);
+        *reinterpret_cast<f32x4 *>(o) = c0a;
+        *reinterpret_cast<f32x4 *>(o + 16) = c1a;
+    }
+}
+}  // namespace
+
+extern "C" size_t smh_model_dense_workspace_bytes(const smh_model *m, int Tc) {
+    return (m && Tc > 0) ? sizeof(float) * 2 * (size_t)Tc * 32 : 0;
+}
+
+extern "C" int smh_model_forward_dense_f32(const smh_model *m, const float *d_fv, int Tc, int shift, void *d_work, size_t work_bytes,
+                                           float *d_out, void *stream) {
+    SMH_REQUIRE(m && d_fv && d_work && d_out, "smh_model_forward_dense_f32: null argument");
+    SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_dense_f32: exists for block_variant 0 only");
+    const int W = m->cfg.patch_size, F = m->cfg.n_feat;
+    SMH_REQUIRE(F % 8 == 0, "smh_model_forward_dense_f32: n_feat=%d must be a multiple of 8 (two halves of whole k steps)", F);
+    SMH_REQUIRE(shift >= 1 && Tc >= W, "smh_model_forward_dense_f32: needs shift >= 1 and at least patch_size=%d frames (Tc=%d, shift=%d); "
+                "shorter chunks are tiled by get_feature_patches and take smh_model_forward_f32", W, Tc, shift);
+    SMH_REQUIRE(work_bytes >= smh_model_dense_workspace_bytes(m, Tc), "smh_model_forward_dense_f32: workspace of %zu bytes, need %zu",
+                work_bytes, smh_model_dense_workspace_bytes(m, Tc));
+    const int nP = smh_num_patches(Tc, W, shift);
+    if (nP <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    float *x0 = static_cast<float *>(d_work);
+    hipLaunchKernelGGL(l0_frames_kernel, dim3((unsigned)((Tc + 63) / 64), 2), dim3(256), 0, st, d_fv, smh_model_w0_ptr(m), x0, F / 2, Tc);
+    int rc = smh::launch_status("l0_frames_kernel");
+    if (rc) return rc;
+    rc = smh_tcn::launch_forward(m, x0, nP, d_out, nullptr, nullptr, st, 1, shift, Tc);
+    return rc ? rc : nP;
 }
 
 extern "C" int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk,

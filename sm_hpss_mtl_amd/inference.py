@@ -11,6 +11,7 @@ layout), the B3_MTL forward, the 501-wide zero-padded median.  No CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -105,12 +106,23 @@ def patch_probabilities(fv, model, W, W_shift=1, output="M", batch_frames=10000)
             break
         col += o.shape[1]
     R = d.shape[0] // 2
-    d = torch.cat([fe.standardize_rows(d[:R]), fe.standardize_rows(d[R:])], dim=0)  # :612-626, whole file
+    # batches longer than a patch skip the (nP, W, 2R) patch tensor (648 MB per 10 000 frames at W = 68, hop 1) when the model has
+    # the entry for it; SMH_DENSE_PATCHES=1 keeps the patch path (A/B, tests)
+    dense = (hasattr(model, "forward_dense") and getattr(model, "block_variant", 1) == 0 and d.shape[0] % 8 == 0
+             and getattr(model, "patch_size", None) == W and not os.environ.get("SMH_DENSE_PATCHES"))
+    d = fe.standardize_rows(d)  # :612-626, whole file; the scaler works row by row, so the two halves are one call
     T = d.shape[1]
     preds = []
     for s in range(0, T, batch_frames):
         e = min(s + batch_frames, T)
         chunk = d[:, s:e].contiguous()
+        if dense and e - s > W:
+            # the same patches without building them (smh_model_forward_dense_f32): each half standardised over the batch as
+            # get_feature_patches does (:647), layer 0 once per frame, every hop-W_shift patch a window of it
+            o = model.forward_dense(fe.standardize_rows(chunk), W_shift)
+            if o.shape[0]:
+                preds.append(o[:, col])
+            continue
         # get_feature_patches on the batch (:647): tile if short, standardise each half over the batch, hop-W_shift
         # patches; written time-major = the transposed TCN input of :660
         h = fe.extract_patches(fe.standardize_rows(chunk[:R])[None], W, W_shift, time_major=True)

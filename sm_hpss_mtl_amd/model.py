@@ -268,6 +268,38 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_f32")
         return out
 
+    def forward_dense(self, fv, shift=1, out=None):
+        """Every hop-`shift` patch of a standardised featuregram batch fv (n_feat, Tc) through the network (dense file-level
+        inference, DAFx12_Speech_Music_Detection_B3_MTL_v2.py:634-665) WITHOUT building the (nP, W, n_feat) patches: layer 0 once
+        per frame, every patch a window of it (`smh_model_forward_dense_f32`).  Returns (nP, out_dim); nP = tools.extract_patches'
+        count for Tc frames.  Needs Tc >= patch_size; shorter batches are tiled by get_feature_patches and go through forward_device."""
+        if not (isinstance(fv, torch.Tensor) and fv.is_cuda and fv.dtype == torch.float32):
+            raise TypeError("forward_dense expects a float32 CUDA tensor")
+        if fv.dim() != 2 or fv.shape[0] != self.n_feat:
+            raise ValueError("expected (%d, Tc), got %s" % (self.n_feat, tuple(fv.shape)))
+        if self.block_variant != 0:
+            raise ValueError("the layer-0 fusion exists for the keras-tcn 2.3.x block only")
+        fv = fv.contiguous()
+        Tc = int(fv.shape[1])
+        self._sync_weights()
+        nP = self.lib.smh_num_patches(Tc, self.patch_size, int(shift)) if Tc >= self.patch_size else -1
+        if nP < 0:
+            raise ValueError("forward_dense needs shift >= 1 and at least patch_size=%d frames, got Tc=%d shift=%d" % (self.patch_size, Tc, shift))
+        if out is None:
+            out = torch.empty((nP, self.out_dim), dtype=torch.float32, device=fv.device)
+        elif tuple(out.shape) != (nP, self.out_dim):
+            raise ValueError("out must be (%d, %d)" % (nP, self.out_dim))
+        if nP == 0:
+            return out
+        nbytes = self.lib.smh_model_dense_workspace_bytes(self._h, Tc)
+        work = torch.empty((nbytes // 4,), dtype=torch.float32, device=fv.device)
+        got = _lib.check(self.lib.smh_model_forward_dense_f32(
+            self._h, C.c_void_p(fv.data_ptr()), Tc, int(shift), C.c_void_p(work.data_ptr()), nbytes, C.c_void_p(out.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_dense_f32")
+        if got != nP:
+            raise RuntimeError("smh_model_forward_dense_f32 produced %d patches, expected %d" % (got, nP))
+        return out
+
     def split_outputs(self, out):
         """(N, out_dim) -> list in Keras output order [S, M, (N,) R, 3C]."""
         res, col = [], 0

@@ -52,6 +52,43 @@ def test_patch_probabilities_vs_oracle(head):
     assert np.max(np.abs(got - ref)) <= 1e-4
 
 
+@pytest.mark.parametrize("W,shift,Tc", [(68, 1, 1000), (68, 3, 517), (99, 1, 400), (99, 7, 99 + 70), (68, 1, 69), (68, 5, 68)])
+def test_forward_dense_equals_forward_on_built_patches(W, shift, Tc):
+    """smh_model_forward_dense_f32 (layer 0 once per frame, every patch a window of it) against the same patches built by
+    extract_patches and run through smh_model_forward_f32: same count (tools.extract_patches' grid, incl. 0 patches at Tc = W for an
+    even W), outputs within 2e-5."""
+    import torch
+    from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
+    from sm_hpss_mtl_amd.model import B3MTL
+    rng = np.random.default_rng(W + shift + Tc)
+    fv = torch.from_numpy(rng.standard_normal((240, Tc)).astype(np.float32)).cuda()
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=3, seed=1)
+    w = b3_mtl.init_weights(seed=5, n_feat=240, patch_size=W, n_classes=3, randomize_bn=True)
+    m.set_weights_dict(w)
+    fe = Frontend(FrontendConfig())
+    got = m.forward_dense(fv, shift)
+    x = fe.extract_patches(fv[None], W, shift, time_major=True)
+    assert got.shape == (x.shape[0], m.out_dim) and x.shape[0] == len(ofe.patch_starts(Tc, W, shift))
+    if x.shape[0]:
+        ref = m.forward_device(x)
+        torch.cuda.synchronize()
+        assert float((got - ref).abs().max()) <= 2e-5
+    with pytest.raises(ValueError):
+        m.forward_dense(fv[:, :W - 1].contiguous(), shift)
+
+
+def test_patch_probabilities_dense_and_patch_paths_agree(monkeypatch):
+    from sm_hpss_mtl_amd import inference as inf
+    from sm_hpss_mtl_amd.model import B3MTL
+    rng = np.random.default_rng(11)
+    fv = (rng.standard_normal((240, 2500)) * 10 - 40).astype(np.float32)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=3, seed=3)
+    dense = inf.patch_probabilities(fv, m, 68, 1, output="M", batch_frames=1000)
+    monkeypatch.setenv("SMH_DENSE_PATCHES", "1")
+    built = inf.patch_probabilities(fv, m, 68, 1, output="M", batch_frames=1000)
+    assert dense.shape == built.shape == (2 * (1000 - 68) + (500 - 68),) and np.max(np.abs(dense - built)) <= 2e-5
+
+
 def test_head_sub_model_as_the_dafx_driver_builds_it():
     """DAFx12...:518-523: Model(trained_model.input, trained_model.get_layer('M').output).predict(x)."""
     from sm_hpss_mtl_amd.lib.proposed_architectures import Model, get_Lemaire_MTL_model
