@@ -416,9 +416,39 @@ class TrainingMixin:
             cb.set_model(self)
             cb.set_writer(rank == 0)
             cb.on_train_begin()
+        # Generator input on a GPU: the NEXT batch is drawn on a side stream as soon as this step's kernels are enqueued, so the front
+        # end that builds it (and, data parallel, nothing else than it: the gradient all-reduce sits on the main stream) runs beside
+        # the training step instead of behind it (SURVEY 8e "overlapped with the next micro-batch's HPSS").  The generator is
+        # advanced exactly steps_per_epoch times per epoch, all of them before the validation pass, as without the side stream:
+        # nothing is drawn across an epoch's end.  SMH_FIT_PREFETCH=0 keeps everything on one stream.
+        side = None
+        if not arrays and torch.cuda.is_available() and os.environ.get("SMH_FIT_PREFETCH", "1") != "0":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())  # whatever the generator's buffers were last used by
+
+        def fetch():
+            if side is None:
+                return next(x) + (None,)
+            with torch.cuda.stream(side):
+                bx_, by_ = next(x)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return bx_, by_, ev
+
+        def adopt(bx_, by_, ev):  # the batch was built on the side stream: order it before, and keep it alive for, the main stream
+            if ev is None:
+                return
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            vals = [bx_] + (list(by_.values()) if isinstance(by_, dict) else list(by_) if isinstance(by_, (list, tuple)) else [by_])
+            for t in vals:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(main)
+
         for ep in range(int(initial_epoch), int(epochs)):
             t0 = time.time()
             acc = None  # device-side sum of the raw per-step losses: one read-back per epoch
+            pending = None
             for s in range(int(steps_per_epoch)):
                 if arrays:
                     sl = slice((s * bs) % len(xs), (s * bs) % len(xs) + bs)
@@ -428,8 +458,12 @@ class TrainingMixin:
                         mine = shard_indices(len(bx), rank, world)
                         bx, by = bx[mine], [a[mine] for a in by]
                 else:
-                    bx, by = next(x)
+                    bx, by, ev = pending if pending is not None else fetch()
+                    pending = None
+                    adopt(bx, by, ev)
                 raw = self._train_step_raw(bx, by)
+                if side is not None and s + 1 < int(steps_per_epoch):
+                    pending = fetch()
                 acc = raw.clone() if acc is None else acc.add_(raw)
             mean_raw = acc / float(max(int(steps_per_epoch), 1))
             if dist is not None:  # the training loss of the GLOBAL batch: mean over the ranks' (equal-sized) shards

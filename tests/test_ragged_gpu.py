@@ -108,6 +108,32 @@ def test_device_generator_yields_the_batches_of_the_sequential_loop(tmp_path):
     assert np.isfinite(h.history["loss"]).all()
 
 
+def test_fit_draws_the_next_batch_on_a_side_stream_with_identical_results(tmp_path, monkeypatch):
+    """fit(generator) builds batch s + 1 on a side stream while step s trains (training.py: fetch / adopt).  Same generator
+    sequence, same seeds, bit-reproducible gradients: the weights after two epochs of three steps equal the one-stream run's."""
+    from sm_hpss_mtl_amd import generators as gen
+    from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
+    folder, files = _dataset(tmp_path)
+
+    def run(tag):
+        P = _params(tmp_path, tag)  # a feature cache of its own: both runs compute every featuregram from the audio
+        np.random.seed(11)
+        torch.manual_seed(11)
+        model, _ = get_Lemaire_MTL_model(TR_STEPS=3, N_MELS=240, n_classes=3, patch_size=68, seed=0)
+        model.deterministic_gradients = True
+        h = model.fit(gen.generator(P, folder, copy.deepcopy(files), 16), steps_per_epoch=3, epochs=2, verbose=0)
+        torch.cuda.synchronize()
+        return h.history["loss"], model.get_weights_dict()
+
+    monkeypatch.setenv("SMH_FIT_PREFETCH", "0")
+    loss0, w0 = run("feat_pf0")
+    monkeypatch.setenv("SMH_FIT_PREFETCH", "1")
+    loss1, w1 = run("feat_pf1")
+    assert loss0 == loss1
+    for k in w0:
+        assert np.array_equal(w0[k], w1[k]), k
+
+
 def test_file_wise_generator_device_path(tmp_path):
     from sm_hpss_mtl_amd import generators as gen
     from sm_hpss_mtl_amd.lib import preprocessing as pp
