@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 3: the featuregram rows of features_half_kernel stored with plain stores (tools/ab/libsmh_featplain.so, -DSMH_PLAIN_FV_STORES on smh_feat.hip only) against the nontemporal stores of the product build
 # step and kernel times alternating, WRITE_SIZE of both
+# A/B library (not tracked): hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DSMH_PLAIN_FV_STORES -Iinclude -c sm_hpss_mtl_amd/csrc/smh_feat.hip -o /tmp/f.o &&
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libsmh_featplain.so /tmp/f.o $(ls sm_hpss_mtl_amd/csrc/build/*.o | grep -v smh_feat.o)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/feat_nt
