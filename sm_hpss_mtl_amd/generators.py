@@ -28,6 +28,7 @@ by one through them, exactly like the reference's loop.
 from __future__ import annotations
 
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -71,6 +72,56 @@ class _ClassBuffer:
         return head, meta
 
 
+# ---- device-resident featuregram cache ------------------------------------------------------------------------------------
+# The reference caches every file's featuregram as <feature_opDir>/<class>/<name>.npy (lib/preprocessing.py:357-363, 446-449) and
+# re-reads it from disk in every later epoch.  An MI355X has 288 GB of HBM: MUSAN's 163.5 h at 100 frames/s x 240 rows x 4 bytes are
+# 56 GB -- the whole corpus fits beside the model.  A cached featuregram is therefore uploaded ONCE and kept on the device (LRU under
+# a byte budget); later batches start from the device copy: no np.load, no host-to-device copy -- and no host synchronisation, which
+# a pageable upload is, so the host can run ahead of the device and fit()'s side stream has something to overlap.  The key carries the
+# file's size and modification time: a rewritten cache file is read again.  SMH_FV_CACHE_GB sets the budget (0 disables; default a
+# quarter of the device's memory).
+_FV_CACHE = OrderedDict()
+_FV_CACHE_BYTES = [0]
+
+
+def _fv_cache_budget():
+    ev = os.environ.get("SMH_FV_CACHE_GB")
+    if ev is not None:
+        return int(float(ev) * 2 ** 30)
+    import torch
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory // 4
+
+
+def fv_cache_clear():
+    """Drop every device-resident featuregram (tests; or to hand the memory back)."""
+    _FV_CACHE.clear()
+    _FV_CACHE_BYTES[0] = 0
+
+
+def _cached_featuregram(path):
+    """The .npy featuregram at `path` as a float32 device tensor, from the device cache when it is there."""
+    import torch
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, torch.cuda.current_device())
+    t = _FV_CACHE.get(key)
+    if t is not None:
+        _FV_CACHE.move_to_end(key)
+        return t
+    t = torch.from_numpy(np.ascontiguousarray(np.load(path, allow_pickle=False), dtype=np.float32)).cuda()
+    budget, nbytes = _fv_cache_budget(), t.numel() * 4
+    if nbytes <= budget:
+        evicted = False
+        while _FV_CACHE and _FV_CACHE_BYTES[0] + nbytes > budget:
+            _, old = _FV_CACHE.popitem(last=False)
+            _FV_CACHE_BYTES[0] -= old.numel() * 4
+            evicted = True
+        if evicted:
+            torch.cuda.synchronize()  # a launch on another stream may still read what was just released
+        _FV_CACHE[key] = t
+        _FV_CACHE_BYTES[0] += nbytes
+    return t
+
+
 def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
     """specs: list of (classname, sp_path, mu_path, target_dB).  Loads / conditions / mixes the signals (the 'next' row in
     front of the path: lib.preprocessing.load_and_preprocess_signal, mix_signals), then ONE ragged pass of the front end.
@@ -84,7 +135,7 @@ def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
     for classname, sp, mu, db in specs:
         cache = pp.feature_cache_path(PARAMS['feature_opDir'], classname, sp, mu, db)
         if os.path.exists(cache):
-            clips.append(("fv", np.load(cache, allow_pickle=False)))
+            clips.append(("fv", cache))
             continue
         if classname == 'speech_music':
             x_sp, _ = pp.load_and_preprocess_signal(sp, PARAMS['Tw'], PARAMS['Ts'])
@@ -107,9 +158,8 @@ def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
                 os.makedirs(os.path.dirname(clips[i][2]), exist_ok=True)
                 np.save(clips[i][2], res["fv"][k].cpu().numpy())
     for i, c in enumerate(clips):
-        if c[0] == "fv":  # cached featuregram: standardise + patches only
-            fv = torch.from_numpy(np.ascontiguousarray(c[1], dtype=np.float32)).cuda()
-            out[i] = fe.patches_from_featuregram(fv, W, shift)
+        if c[0] == "fv":  # cached featuregram (device copy after its first use): standardise + patches only
+            out[i] = fe.patches_from_featuregram(_cached_featuregram(c[1]), W, shift)
     return out
 
 

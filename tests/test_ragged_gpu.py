@@ -134,6 +134,56 @@ def test_fit_draws_the_next_batch_on_a_side_stream_with_identical_results(tmp_pa
         assert np.array_equal(w0[k], w1[k]), k
 
 
+def test_device_resident_featuregram_cache(tmp_path, monkeypatch):
+    """generators._cached_featuregram: a cached .npy featuregram is uploaded once and served from the device afterwards -- same
+    batches as with the cache off (SMH_FV_CACHE_GB=0), a rewritten file is read again, the byte budget evicts the oldest entry."""
+    from sm_hpss_mtl_amd import generators as gen
+    folder, files = _dataset(tmp_path)
+    P = _params(tmp_path, "feat_dc")
+
+    def batches(n):
+        np.random.seed(5)
+        torch.manual_seed(5)
+        g = gen.generator(P, folder, copy.deepcopy(files), 16)
+        return [next(g) for _ in range(n)]
+
+    monkeypatch.setenv("SMH_FV_CACHE_GB", "0")
+    batches(3)  # computes and writes the .npy cache of every file the three batches touch: from here on all runs take the cached path
+    gen.fv_cache_clear()
+    off = batches(3)
+    assert len(gen._FV_CACHE) == 0
+    monkeypatch.setenv("SMH_FV_CACHE_GB", "1")
+    on1 = batches(3)   # fills the device cache
+    n_entries = len(gen._FV_CACHE)
+    assert n_entries > 0
+    on2 = batches(3)   # served from it
+    assert len(gen._FV_CACHE) == n_entries
+    for a, b, c in zip(off, on1, on2):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0])
+        assert all(np.array_equal(a[1][k], c[1][k]) for k in a[1])
+    # a rewritten file is a new entry (size / mtime are part of the key)
+    path = next(iter(gen._FV_CACHE))[0]
+    fv = np.load(path)
+    np.save(path, (fv * 0.5).astype(np.float32))
+    os.utime(path, ns=(os.stat(path).st_atime_ns, os.stat(path).st_mtime_ns + 10_000_000))
+    t = gen._cached_featuregram(path)
+    assert torch.equal(t.cpu(), torch.from_numpy(fv * 0.5)) and len(gen._FV_CACHE) == n_entries + 1
+    # a byte budget of the largest of three featuregrams: the newest file is always resident, the total never exceeds the budget,
+    # and what does not fit beside it has been evicted oldest first
+    gen.fv_cache_clear()
+    paths = sorted(str(q) for q in (tmp_path / "feat_dc").rglob("*.npy"))[:3]
+    sizes = [np.load(q).nbytes for q in paths]
+    budget = max(sizes)
+    monkeypatch.setenv("SMH_FV_CACHE_GB", repr(budget / 2 ** 30))
+    for q in paths:
+        gen._cached_featuregram(q)
+        keys = [k[0] for k in gen._FV_CACHE]
+        assert keys[-1] == os.path.abspath(q) and gen._FV_CACHE_BYTES[0] <= budget
+        assert keys == [os.path.abspath(r) for r in paths[paths.index(q) + 1 - len(keys):paths.index(q) + 1]]  # a suffix of the files so far
+    assert sum(sizes) > budget and len(gen._FV_CACHE) < 3
+    gen.fv_cache_clear()
+
+
 def test_file_wise_generator_device_path(tmp_path):
     from sm_hpss_mtl_amd import generators as gen
     from sm_hpss_mtl_amd.lib import preprocessing as pp

@@ -1,0 +1,28 @@
+"""GPU timing of model.fit(generator) on the synthetic .npy folds of tests/test_ragged_gpu.py once the featuregram cache is warm (what
+every epoch after the first looks like): ms per fit step = generator batch (3 x 16 patches) + training step.  Environment:
+SMH_FV_CACHE_GB=0 re-reads the .npy files every batch (the reference's way), default keeps them on the device; SMH_FIT_PREFETCH=0 / 1."""
+import copy, os, sys, tempfile, time
+from pathlib import Path
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_ragged_gpu as T  # noqa: E402  (its synthetic dataset and PARAMS)
+from sm_hpss_mtl_amd import generators as gen  # noqa: E402
+from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model  # noqa: E402
+
+tmp = Path(tempfile.mkdtemp())
+folder, files = T._dataset(tmp)
+P = T._params(tmp, "feat")
+np.random.seed(1)
+torch.manual_seed(1)
+model, _ = get_Lemaire_MTL_model(TR_STEPS=3, N_MELS=240, n_classes=3, patch_size=68, seed=0)
+g = gen.generator(P, folder, copy.deepcopy(files), 16)
+model.fit(g, steps_per_epoch=40, epochs=1, verbose=0)  # fills the .npy cache (and the device cache), warms up
+torch.cuda.synchronize()
+K = 300
+t0 = time.perf_counter()
+model.fit(g, steps_per_epoch=K, epochs=1, verbose=0)
+torch.cuda.synchronize()
+print("SMH_FV_CACHE_GB=%s SMH_FIT_PREFETCH=%s: %.3f ms per fit step (generator batch of 48 patches + training step); %d featuregrams on the device" % (
+    os.environ.get("SMH_FV_CACHE_GB", "default"), os.environ.get("SMH_FIT_PREFETCH", "1"), (time.perf_counter() - t0) / K * 1e3, len(gen._FV_CACHE)), flush=True)
