@@ -294,12 +294,20 @@ class Frontend:
         for n in lens:
             offs.append(o)
             o += (n + 3) // 4 * 4  # next clip starts on a 16-byte boundary
-        audio = torch.zeros(max(o, 1), dtype=torch.float32, device=dev)
-        for c, n, of in zip(clips, lens, offs):
-            t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
-            if t.dim() != 1:
+        for c in clips:
+            if c.ndim != 1:
                 raise ValueError("run_ragged: every clip must be 1-D")
-            audio[of:of + n] = t.to(device=dev, dtype=torch.float32)
+        if all(isinstance(c, np.ndarray) for c in clips):
+            # host clips: laid out in ONE host buffer and uploaded by ONE copy (a copy per clip is a host synchronisation per clip)
+            host = np.zeros(max(o, 1), dtype=np.float32)
+            for c, n, of in zip(clips, lens, offs):
+                host[of:of + n] = c
+            audio = torch.from_numpy(host).to(device=dev)
+        else:
+            audio = torch.zeros(max(o, 1), dtype=torch.float32, device=dev)
+            for c, n, of in zip(clips, lens, offs):
+                t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
+                audio[of:of + n] = t.to(device=dev, dtype=torch.float32)
         h_off = (C.c_longlong * B)(*offs)
         h_len = (C.c_int * B)(*lens)
         fv_off, p_off = (C.c_longlong * (B + 1))(), (C.c_longlong * (B + 1))()

@@ -98,8 +98,9 @@ def fv_cache_clear():
     _FV_CACHE_BYTES[0] = 0
 
 
-def _cached_featuregram(path):
-    """The .npy featuregram at `path` as a float32 device tensor, from the device cache when it is there."""
+def _cached_featuregram(path, fresh=None):
+    """The .npy featuregram at `path` as a float32 device tensor, from the device cache when it is there.
+    fresh: the device tensor that has just been written to `path` (the file need not be read back to enter the cache)."""
     import torch
     st = os.stat(path)
     key = (os.path.abspath(path), st.st_mtime_ns, st.st_size, torch.cuda.current_device())
@@ -107,7 +108,10 @@ def _cached_featuregram(path):
     if t is not None:
         _FV_CACHE.move_to_end(key)
         return t
-    t = torch.from_numpy(np.ascontiguousarray(np.load(path, allow_pickle=False), dtype=np.float32)).cuda()
+    if fresh is not None:
+        t = fresh.detach().to(dtype=torch.float32).clone()  # (a copy: the ragged pass hands out views of one buffer)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.load(path, allow_pickle=False), dtype=np.float32)).cuda()
     budget, nbytes = _fv_cache_budget(), t.numel() * 4
     if nbytes <= budget:
         evicted = False
@@ -157,6 +161,7 @@ def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
             if PARAMS.get('save_features', True):  # get_featuregram(save_feat=True): the reference's .npy cache
                 os.makedirs(os.path.dirname(clips[i][2]), exist_ok=True)
                 np.save(clips[i][2], res["fv"][k].cpu().numpy())
+                _cached_featuregram(clips[i][2], fresh=res["fv"][k])  # ... and stays on the device for the epochs to come
     for i, c in enumerate(clips):
         if c[0] == "fv":  # cached featuregram (device copy after its first use): standardise + patches only
             out[i] = fe.patches_from_featuregram(_cached_featuregram(c[1]), W, shift)
