@@ -237,4 +237,5 @@ class CnnMTL(CnnTrainingMixin, ModelSurfaceMixin):
         elif x.dtype != torch.float32:
             x = x.float()
         out = self.forward_device(x.cuda(), dtype=dtype)
-        return [o.cpu().numpy() for o in self.split_outputs(out)]
+        host = out.cpu().numpy()  # one copy for all outputs
+        return [np.ascontiguousarray(o) for o in self.split_outputs(host)]

@@ -317,7 +317,8 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
             x = x.float()
         out = self.forward_device(x.cuda(), dtype=dtype)
         self.check_status()  # the forward is stream-ordered: a device-side give-up must become an exception, not a result
-        return [o.cpu().numpy() for o in self.split_outputs(out)]
+        host = out.cpu().numpy()  # ONE copy for all outputs (a copy per output is a host synchronisation per output)
+        return [np.ascontiguousarray(o) for o in self.split_outputs(host)]
 
     def check_status(self):
         """Wait for the current stream and raise RuntimeError if a forward kernel recorded in the model's device error word

@@ -336,7 +336,9 @@ class TrainingMixin:
 
     # ---- evaluate ---------------------------------------------------------------------------------
     def _losses_inference(self, x, y):
-        """Losses / accuracy of one batch in inference mode (Keras `evaluate` semantics)."""
+        """Losses / accuracy of one batch in inference mode (Keras `evaluate` semantics).  The heads' kernel-regulariser penalty
+        depends on the weights only: `evaluate` computes it once for all its batches (`_eval_l2`) instead of downloading the weight
+        vector behind every one of them."""
         outs = self.predict(x)
         yl = y if isinstance(y, (list, tuple)) else [y[k] for k in self.output_names]
         eps = 1e-7
@@ -353,7 +355,14 @@ class TrainingMixin:
                 per.append(float(np.mean(-(t * np.log(oc + eps) + (1 - t) * np.log(1 - oc + eps)))))
         lw = [float((self.loss_weights or {}).get(n, 1.0)) for n in self.output_names]
         acc = float(np.mean(outs[-1].argmax(1) == np.asarray(yl[-1]).argmax(1)))
-        return [sum(a * b for a, b in zip(lw, per)) + self._l2_penalty()] + per + [acc]
+        cache = getattr(self, "_eval_l2", None)  # a dict while `evaluate` runs: the penalty is computed by its first batch
+        if cache is None:
+            l2 = self._l2_penalty()
+        else:
+            if "v" not in cache:
+                cache["v"] = self._l2_penalty()
+            l2 = cache["v"]
+        return [sum(a * b for a, b in zip(lw, per)) + l2] + per + [acc]
 
     def evaluate(self, x=None, y=None, steps=None, verbose=0, batch_size=None, **kwargs):
         """model.evaluate(generator, steps) or evaluate(x, y) -> list matching `metrics_names`."""
@@ -364,20 +373,24 @@ class TrainingMixin:
         # turns the shard means into the mean over the global batch -- the number a single device would report, and the SAME
         # number on every rank (EarlyStopping / ModelCheckpoint decide on it).  Single process: a plain mean over the batches.
         dist = process_group()
-        if y is not None:
-            v = np.array(self._losses_inference(x, y), np.float64)
-            rows = float(len(x))
-            tot, cnt = v * rows, rows
-        else:
-            if steps is None:
-                raise ValueError("evaluate(generator) needs steps=")
-            tot, cnt = None, 0.0
-            for _ in range(int(steps)):
-                bx, by = next(x)
-                rows = float(len(bx)) if dist is not None else 1.0  # Keras averages the batch values (equal batch sizes)
-                v = np.array(self._losses_inference(bx, by), np.float64) * rows
-                tot = v if tot is None else tot + v
-                cnt += rows
+        self._eval_l2 = {}  # the weights do not change while evaluating: one penalty for all batches (see _losses_inference)
+        try:
+            if y is not None:
+                v = np.array(self._losses_inference(x, y), np.float64)
+                rows = float(len(x))
+                tot, cnt = v * rows, rows
+            else:
+                if steps is None:
+                    raise ValueError("evaluate(generator) needs steps=")
+                tot, cnt = None, 0.0
+                for _ in range(int(steps)):
+                    bx, by = next(x)
+                    rows = float(len(bx)) if dist is not None else 1.0  # Keras averages the batch values (equal batch sizes)
+                    v = np.array(self._losses_inference(bx, by), np.float64) * rows
+                    tot = v if tot is None else tot + v
+                    cnt += rows
+        finally:
+            self._eval_l2 = None
         if dist is not None:
             red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
             tot, cnt = red[:-1], red[-1]

@@ -24,5 +24,16 @@ K = 300
 t0 = time.perf_counter()
 model.fit(g, steps_per_epoch=K, epochs=1, verbose=0)
 torch.cuda.synchronize()
+fit_ms = (time.perf_counter() - t0) / K * 1e3
+te = time.perf_counter()
+model.evaluate(g, steps=K)
+torch.cuda.synchronize()
+ev_ms = (time.perf_counter() - te) / K * 1e3
+tl = time.perf_counter()
+for _ in range(50):
+    model._l2_penalty()
+l2_ms = (time.perf_counter() - tl) / 50 * 1e3
+print("  evaluate(generator, steps=%d): %.3f ms per step (the heads' l2 penalty -- a download of the weight vector, %.3f ms -- once per call; "
+      "it used to follow every batch)" % (K, ev_ms, l2_ms), flush=True)
 print("SMH_FV_CACHE_GB=%s SMH_FIT_PREFETCH=%s: %.3f ms per fit step (generator batch of 48 patches + training step); %d featuregrams on the device" % (
-    os.environ.get("SMH_FV_CACHE_GB", "default"), os.environ.get("SMH_FIT_PREFETCH", "1"), (time.perf_counter() - t0) / K * 1e3, len(gen._FV_CACHE)), flush=True)
+    os.environ.get("SMH_FV_CACHE_GB", "default"), os.environ.get("SMH_FIT_PREFETCH", "1"), fit_ms, len(gen._FV_CACHE)), flush=True)
