@@ -25,8 +25,11 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
 int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, const float *perc, int B, int T, int W,
                          int shift, int nP, float *fv, float *patches, const float *w0, float *x0p, hipStream_t st);
 // w0 / x0p non-null: also emit this half's share of the network's first Conv1D (see smh_features_l0_f32)
+// scratch (scratch_bytes): device memory the long-clip path may use for its standardised copy of the featuregram (2 * B * rows * T
+// floats) instead of a stream-ordered allocation per call -- smh_frontend_f32 hands it the S / perc part of its workspace, dead by then
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
-                     float *patches, hipStream_t st, const float *w0 = nullptr, float *x0p = nullptr);
+                     float *patches, hipStream_t st, const float *w0 = nullptr, float *x0p = nullptr, void *scratch = nullptr,
+                     size_t scratch_bytes = 0);
 
 }  // namespace smh_feat
 

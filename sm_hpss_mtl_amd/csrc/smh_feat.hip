@@ -1298,7 +1298,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
 }
 
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,
-                     float *patches, hipStream_t st, const float *w0, float *x0p) {
+                     float *patches, hipStream_t st, const float *w0, float *x0p, void *scratch, size_t scratch_bytes) {
     const int rows = c->feat_rows;
     const size_t lds = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows);
     if (x0p && (lds > 150 * 1024 || rows % 4 != 0 || rows > 128))
@@ -1318,7 +1318,9 @@ int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int
         if (!patches || nP <= 0) return SMH_OK;
         float *tmp = nullptr;
         const size_t n_rows = (size_t)2 * B * rows;
-        SMH_CHECK_HIP(hipMallocAsync((void **)&tmp, n_rows * T * sizeof(float), st));
+        const bool own = !(scratch && scratch_bytes >= n_rows * T * sizeof(float));  // no caller scratch: a stream-ordered allocation
+        if (own) SMH_CHECK_HIP(hipMallocAsync((void **)&tmp, n_rows * T * sizeof(float), st));
+        else tmp = static_cast<float *>(scratch);
         hipLaunchKernelGGL(standardize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, (const float *)fv,
                            (int)n_rows, T, tmp);
         const size_t per_clip = (size_t)nP * 2 * rows * W;
@@ -1327,7 +1329,7 @@ int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int
         hipLaunchKernelGGL(extract_patches_kernel, dim3((unsigned)nb, B), dim3(256), 0, st, (const float *)tmp, 2 * rows, T,
                            smh_tiled_frames(T, W), W, shift, nP, 1, patches);
         int rc = smh::launch_status("long-clip standardise / patch kernels");
-        SMH_CHECK_HIP(hipFreeAsync(tmp, st));
+        if (own) SMH_CHECK_HIP(hipFreeAsync(tmp, st));
         return rc;
     }
     if (x0p) {

@@ -137,8 +137,10 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
     }
     rc = smh_feat::launch_hp_feat(ctx, S, harm, perc, tm, B, T, d_fv, (int *)maxkeys, st);
     if (rc) return rc;
+    // (the workspace's S and perc parts -- 2 * spec bytes at its start, also when the caller took the taps into buffers of its own --
+    // are dead behind the feature kernel: the long-clip patch path standardises into them instead of allocating per call)
     rc = smh_feat::launch_std_patch(ctx, d_fv, (const int *)maxkeys, B, T, W > 0 ? W : 1, shift > 0 ? shift : 1, nP,
-                                    nP > 0 ? d_patches : nullptr, st);
+                                    nP > 0 ? d_patches : nullptr, st, nullptr, nullptr, (d_S || d_perc) ? nullptr : w, 2 * spec);
     if (rc) return rc;
     return nP;
 }
