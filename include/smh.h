@@ -261,6 +261,15 @@ int smh_features_l0_f32(const smh_ctx *ctx, const float *d_S, const float *d_har
                         int B, int T, int W, int shift, float *d_fv, float *d_patches, const float *d_w0, float *d_x0p,
                         int32_t *d_maxkeys, void *stream);
 int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk, void *stream);
+/* model.evaluate's arithmetic for one batch (Proposed_Work_Results.py:160-165 losses, 683-687 evaluate): from d_out (N, out_dim) as
+ * smh_model_forward_f32 wrote it and d_targets (N, out_dim) in the same column order [S | M | (N) | R | 3C], the batch means of the
+ * inference-mode losses -- binary cross-entropy on the sigmoid heads, mean squared error on 'R', categorical cross-entropy on '3C', all
+ * with Keras' 1e-7 clipping, float64 arithmetic --, the '3C' accuracy and the total loss sum_i h_loss_weights[i] * loss_i + l2_penalty
+ * (h_loss_weights: n_heads + 1 host doubles in output order; l2_penalty: the heads' kernel-regulariser term, a function of the weights
+ * only), each multiplied by `weight` and ADDED to d_sums[n_heads + 3] = [total | head losses in output order | 3C loss | 3C accuracy]
+ * (float64, zeroed by the caller): a validation pass accumulates on the device and reads back once. */
+int smh_model_eval_losses_f32(const smh_model *m, const float *d_out, const float *d_targets, int N, double weight,
+                              const double *h_loss_weights, double l2_penalty, double *d_sums, void *stream);
 /* Dense file-level inference: the per-batch body of `patch_probability_generator`,
  * DAFx12_Speech_Music_Detection_B3_MTL_v2.py:634-665 -- every hop-`shift` patch of a 10 000-frame batch of one file's featuregram
  * through model.predict.  d_fv (n_feat, Tc) float32: the batch as get_feature_patches leaves it in front of the patch extraction

@@ -95,6 +95,7 @@ SIGNATURES = {
     "smh_model_w0_ptr": (_vp, [_vp]),
     "smh_features_l0_f32": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _vp]),
     "smh_model_forward_x0_f32": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
+    "smh_model_eval_losses_f32": (_i, [_vp, _fp, _fp, _i, C.c_double, C.POINTER(C.c_double), C.c_double, _vp, _vp]),
     "smh_model_dense_workspace_bytes": (_sz, [_vp, _i]),
     "smh_model_forward_dense_f32": (_i, [_vp, _fp, _i, _i, _vp, _sz, _fp, _vp]),
     "smh_model_forward_bf16": (_i, [_vp, _fp, _i, _fp, _vp]),

@@ -1438,6 +1438,89 @@ extern "C" int smh_model_forward_dense_f32(const smh_model *m, const float *d_fv
     return rc ? rc : nP;
 }
 
+// ---- model.evaluate's per-batch arithmetic on the device (Keras inference-mode losses of Proposed_Work_Results.py:160-165, 683-687) ----
+// One 256-thread workgroup per batch: for every output the batch-mean loss -- binary cross-entropy on the sigmoid heads and categorical
+// cross-entropy on '3C' with Keras' 1e-7 clipping, mean squared error on 'R' -- and the '3C' accuracy, in float64 like the host
+// arithmetic it replaces (training.py: _losses_inference), ADDED (times `weight`) to d_sums: the caller reads the sums
+// back once per evaluate call instead of synchronising behind every batch.
+namespace {
+struct EvalArgs {
+    int N, n_heads, n_classes, out_dim;
+    int head_odim[kMaxHeads], head_sigmoid[kMaxHeads];
+    double weight, l2, lw[kMaxHeads + 1];
+};
+__global__ void __launch_bounds__(256) eval_losses_kernel(EvalArgs a, const float *__restrict__ out, const float *__restrict__ tgt,
+                                                          double *__restrict__ sums) {
+    __shared__ double red[256];
+    __shared__ double mean[kMaxHeads + 2];
+    const int tid = threadIdx.x;
+    const double eps = 1e-7;
+    int c3 = 0;
+    for (int h = 0; h < a.n_heads; ++h) c3 += a.head_odim[h];
+    int col = 0;
+    for (int slot = 0; slot < a.n_heads + 2; ++slot) {
+        double acc = 0.0;
+        const int od = slot < a.n_heads ? a.head_odim[slot] : a.n_classes;
+        const int c0 = slot < a.n_heads ? col : c3;
+        for (int r = tid; r < a.N; r += 256) {
+            const float *o = out + (size_t)r * a.out_dim + c0, *t = tgt + (size_t)r * a.out_dim + c0;
+            if (slot < a.n_heads) {
+                for (int c = 0; c < od; ++c) {
+                    const double ov = (double)o[c], tv = (double)t[c];
+                    if (a.head_sigmoid[slot]) {
+                        const double oc = fmin(fmax(ov, eps), 1.0 - eps);
+                        acc -= tv * log(oc + eps) + (1.0 - tv) * log(1.0 - oc + eps);
+                    } else {
+                        acc += (ov - tv) * (ov - tv);
+                    }
+                }
+            } else if (slot == a.n_heads) {
+                double sum = 0.0;
+                for (int c = 0; c < od; ++c) sum += (double)o[c];
+                for (int c = 0; c < od; ++c) acc -= (double)t[c] * log(fmin(fmax((double)o[c] / sum, eps), 1.0 - eps));
+            } else {
+                int bo = 0, bt = 0;  // first maximum, like numpy's argmax
+                for (int c = 1; c < od; ++c) {
+                    if (o[c] > o[bo]) bo = c;
+                    if (t[c] > t[bt]) bt = c;
+                }
+                acc += bo == bt ? 1.0 : 0.0;
+            }
+        }
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) mean[slot] = red[0] / (slot < a.n_heads ? (double)a.N * od : (double)a.N);
+        __syncthreads();
+        if (slot < a.n_heads) col += od;
+    }
+    if (tid == 0) {
+        // the batch's values first, then their weight -- the order of the host loop this replaces (training.py: _losses_inference,
+        // evaluate), so that a one-rank data-parallel pass (row-weighted) and a plain one agree to the bit as they did there
+        double total = 0.0;
+        for (int i = 0; i <= a.n_heads; ++i) total += a.lw[i] * mean[i];
+        total += a.l2;
+        sums[0] += a.weight * total;
+        for (int i = 0; i < a.n_heads + 2; ++i) sums[1 + i] += a.weight * mean[i];
+    }
+}
+}  // namespace
+
+extern "C" int smh_model_eval_losses_f32(const smh_model *m, const float *d_out, const float *d_targets, int N, double weight,
+                                         const double *h_loss_weights, double l2_penalty, double *d_sums, void *stream) {
+    SMH_REQUIRE(m && d_out && d_targets && d_sums && h_loss_weights, "smh_model_eval_losses_f32: null argument");
+    SMH_REQUIRE(N >= 1, "smh_model_eval_losses_f32: N=%d", N);
+    EvalArgs a;
+    a.N = N, a.n_heads = m->n_heads, a.n_classes = m->cfg.n_classes, a.out_dim = m->out_dim, a.weight = weight, a.l2 = l2_penalty;
+    for (int i = 0; i < kMaxHeads; ++i) a.head_odim[i] = m->head_odim[i], a.head_sigmoid[i] = m->head_sigmoid[i];
+    for (int i = 0; i <= kMaxHeads; ++i) a.lw[i] = i <= m->n_heads ? h_loss_weights[i] : 0.0;
+    hipLaunchKernelGGL(eval_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, d_out, d_targets, d_sums);
+    return smh::launch_status("eval_losses_kernel");
+}
+
 extern "C" int smh_model_forward_x0_f32(const smh_model *m, const float *d_x0p, int N, float *d_out, float *d_trunk,
                                         void *stream) {
     SMH_REQUIRE(m && d_x0p && d_out, "smh_model_forward_x0_f32: null argument");

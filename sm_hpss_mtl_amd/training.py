@@ -373,6 +373,12 @@ class TrainingMixin:
         # turns the shard means into the mean over the global batch -- the number a single device would report, and the SAME
         # number on every rank (EarlyStopping / ModelCheckpoint decide on it).  Single process: a plain mean over the batches.
         dist = process_group()
+        if self._device_evaluate_ok():
+            tot, cnt = self._evaluate_device(x, y, steps, dist is not None)
+            if dist is not None:
+                red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
+                tot, cnt = red[:-1], red[-1]
+            return list(tot / max(cnt, 1.0))
         self._eval_l2 = {}  # the weights do not change while evaluating: one penalty for all batches (see _losses_inference)
         try:
             if y is not None:
@@ -395,6 +401,45 @@ class TrainingMixin:
             red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
             tot, cnt = red[:-1], red[-1]
         return list(tot / max(cnt, 1.0))
+
+    def _device_evaluate_ok(self):
+        """B3_MTL with libsmh's evaluate kernel: the per-batch losses are summed on the device (smh_model_eval_losses_f32)."""
+        return (getattr(self, "_TRAINER_API", ("",))[0] == "smh_trainer_create" and hasattr(self, "forward_device")
+                and hasattr(getattr(self, "lib", None), "smh_model_eval_losses_f32") and getattr(self, "block_variant", 0) == 0
+                and os.environ.get("SMH_EVAL_HOST", "0") != "1")
+
+    def _evaluate_device(self, x, y, steps, weighted):
+        """evaluate() without a host round trip per batch: forward, then `smh_model_eval_losses_f32` adds the batch's mean losses and
+        accuracy (float64, Keras' clipping: the arithmetic of `_losses_inference`) to device sums; ONE read-back at the end.
+        Returns (unnormalised sums in metrics order, total weight) like the host loop.  SMH_EVAL_HOST=1 keeps the host loop."""
+        nh = len(self.output_names) - 1
+        sums = torch.zeros(nh + 3, dtype=torch.float64, device="cuda")  # [total | per-output losses | 3C accuracy]
+        cnt = 0.0
+        lw = (C.c_double * (nh + 1))(*[float((self.loss_weights or {}).get(n, 1.0)) for n in self.output_names])
+        l2 = float(self._l2_penalty())  # the weights do not change while evaluating
+
+        def one(bx, by, by_rows):
+            if isinstance(bx, np.ndarray):
+                bx = torch.from_numpy(np.ascontiguousarray(bx, dtype=np.float32))
+            out = self.forward_device(bx.to(device="cuda", dtype=torch.float32))
+            tgt = by if (isinstance(by, torch.Tensor) and by.is_cuda and by.dim() == 2) else self.pack_targets(by)
+            if tgt.shape[0] != out.shape[0]:
+                raise ValueError("%d inputs but %d target rows" % (out.shape[0], tgt.shape[0]))
+            w = float(out.shape[0]) if by_rows else 1.0  # Keras averages the batch values; data parallel: row-weighted (see evaluate)
+            _lib.check(self.lib.smh_model_eval_losses_f32(self._h, C.c_void_p(out.data_ptr()), C.c_void_p(tgt.data_ptr()), out.shape[0],
+                                                          C.c_double(w), lw, C.c_double(l2), C.c_void_p(sums.data_ptr()), _cur_stream()),
+                       "smh_model_eval_losses_f32")
+            return w
+
+        if y is not None:
+            cnt = one(x, y, True)  # arrays: one batch, weighted by its rows like the host path
+        else:
+            if steps is None:
+                raise ValueError("evaluate(generator) needs steps=")
+            for _ in range(int(steps)):
+                cnt += one(*next(x), weighted)
+        self.check_status()  # one synchronisation for the whole pass; a device-side give-up raises here
+        return sums.cpu().numpy(), cnt  # already in metrics order: [loss, <per-output losses>, 3C_accuracy]
 
     # ---- fit ------------------------------------------------------------------------------------------
     def _train_step_raw(self, bx, by):

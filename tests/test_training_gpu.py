@@ -123,6 +123,38 @@ def test_fit_evaluate_surface(tmp_path):
     assert abs(float(np.mean(-np.sum(vy["3C"] * np.log(np.clip(outs[-1], 1e-7, 1)), axis=1))) - after[4]) < 1e-3
 
 
+@pytest.mark.parametrize("ncls", [3, 5])
+def test_evaluate_on_the_device_equals_the_host_arithmetic(ncls, monkeypatch):
+    """model.evaluate sums its per-batch losses on the device (smh_model_eval_losses_f32: float64, Keras' clipping) and reads back once;
+    SMH_EVAL_HOST=1 keeps the host loop (predict + numpy float64 per batch).  Same numbers to 1e-9 relative, from a generator (batches of
+    different sizes, loss weights set) and from arrays; outputs clipped at both ends of the sigmoid range are in the batches."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, _, _ = _problem(ncls, 37, seed=4)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls, seed=0)
+    w["S/out/bias"] = w["S/out/bias"] + 40.0   # saturate one sigmoid head: exercises the clipping at 1 - 1e-7
+    w["M/out/bias"] = w["M/out/bias"] - 40.0   # ... and at 1e-7
+    m.set_weights_dict(w)
+    m.loss_weights = {"S": 0.5, "3C": 2.0}
+    names = m.output_names
+
+    def gen():
+        k = 0
+        while True:
+            n = (5, 12, 20)[k % 3]
+            sl = slice((7 * k) % 17, (7 * k) % 17 + n)
+            yield x[sl], {q: y[q][sl] for q in names}
+            k += 1
+
+    dev_g = m.evaluate(gen(), steps=5)
+    dev_a = m.evaluate(x, [y[q] for q in names])
+    monkeypatch.setenv("SMH_EVAL_HOST", "1")
+    host_g = m.evaluate(gen(), steps=5)
+    host_a = m.evaluate(x, [y[q] for q in names])
+    assert len(dev_g) == len(host_g) == len(m.metrics_names)
+    np.testing.assert_allclose(dev_g, host_g, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dev_a, host_a, rtol=1e-9, atol=1e-12)
+
+
 def test_end_to_end_synthetic_training_batches():
     """Config-4 shaped path: synthetic audio -> HIP front end -> patches + reference labels -> fit."""
     from sm_hpss_mtl_amd.batching import synthetic_batch

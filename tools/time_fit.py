@@ -29,11 +29,17 @@ te = time.perf_counter()
 model.evaluate(g, steps=K)
 torch.cuda.synchronize()
 ev_ms = (time.perf_counter() - te) / K * 1e3
+os.environ["SMH_EVAL_HOST"] = "1"
+te = time.perf_counter()
+model.evaluate(g, steps=K)
+torch.cuda.synchronize()
+ev_host_ms = (time.perf_counter() - te) / K * 1e3
+del os.environ["SMH_EVAL_HOST"]
 tl = time.perf_counter()
 for _ in range(50):
     model._l2_penalty()
 l2_ms = (time.perf_counter() - tl) / 50 * 1e3
-print("  evaluate(generator, steps=%d): %.3f ms per step (the heads' l2 penalty -- a download of the weight vector, %.3f ms -- once per call; "
-      "it used to follow every batch)" % (K, ev_ms, l2_ms), flush=True)
+print("  evaluate(generator, steps=%d): %.3f ms per step with the losses summed on the device, %.3f ms with the host loop (SMH_EVAL_HOST=1); "
+      "one _l2_penalty() = %.3f ms" % (K, ev_ms, ev_host_ms, l2_ms), flush=True)
 print("SMH_FV_CACHE_GB=%s SMH_FIT_PREFETCH=%s: %.3f ms per fit step (generator batch of 48 patches + training step); %d featuregrams on the device" % (
     os.environ.get("SMH_FV_CACHE_GB", "default"), os.environ.get("SMH_FIT_PREFETCH", "1"), fit_ms, len(gen._FV_CACHE)), flush=True)
