@@ -138,7 +138,7 @@ class CnnMTL(CnnTrainingMixin, ModelSurfaceMixin):
         if self._device_newer:
             flat = np.empty(self.count_params(), np.float32)
             _lib.check(self.lib.smh_cnn_get_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                    _lib.current_stream()),
                        "smh_cnn_get_weights")
             for name, shape, off in self._spec:
                 self.weights[name] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
@@ -193,7 +193,7 @@ class CnnMTL(CnnTrainingMixin, ModelSurfaceMixin):
         if self._dirty:
             flat = np.concatenate([self.weights[n].ravel() for n, _, _ in self._spec]).astype(np.float32)
             _lib.check(self.lib.smh_cnn_set_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                    _lib.current_stream()),
                        "smh_cnn_set_weights")
             self._dirty = False
 
@@ -219,7 +219,7 @@ class CnnMTL(CnnTrainingMixin, ModelSurfaceMixin):
         _lib.check(fn(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if features is None else C.c_void_p(features.data_ptr()), C.c_void_p(work.data_ptr()), work.numel(),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_cnn_forward_" + dtype)
+            _lib.current_stream()), "smh_cnn_forward_" + dtype)
         return out
 
     def split_outputs(self, out):

@@ -21,7 +21,7 @@ def fresh_seed() -> int:
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream()
 
 
 def add_normal_noise(x: "torch.Tensor", scale: float, seed=None, offset=None, out=None) -> "torch.Tensor":

@@ -52,7 +52,7 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream()
 
 
 def _out(out, key, shape, dtype, dev):

@@ -140,7 +140,7 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         if self._device_newer:
             flat = np.empty(self.count_params(), np.float32)
             _lib.check(self.lib.smh_model_get_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
-                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                      _lib.current_stream()),
                        "smh_model_get_weights")
             o = 0
             for name, shape, _, _ in self._spec:
@@ -203,7 +203,7 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         if self._dirty:
             flat = np.concatenate([self.weights[n].ravel() for n, _, _, _ in self._spec]).astype(np.float32)
             _lib.check(self.lib.smh_model_set_weights(self._h, flat.ctypes.data_as(C.c_void_p), flat.size,
-                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                      _lib.current_stream()),
                        "smh_model_set_weights")
             self._dirty = False
 
@@ -229,14 +229,14 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
                 raise ValueError("the trunk tap is only available on the f32 path")
             _lib.check(self.lib.smh_model_forward_bf16_ex(
                 self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()), 1,
-                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_bf16")
+                _lib.current_stream()), "smh_model_forward_bf16")
             return out
         if dtype != "f32":
             raise ValueError("dtype must be 'f32' or 'bf16' (split bf16 operands), got %r" % (dtype,))
         _lib.check(self.lib.smh_model_forward_f32(
             self._h, C.c_void_p(x.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_f32")
+            _lib.current_stream()), "smh_model_forward_f32")
         return out
 
     def forward_from_x0(self, x0p, out=None, trunk=None, dtype="f32"):
@@ -258,14 +258,14 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
                 raise ValueError("the trunk tap is only available on the f32 path")
             _lib.check(self.lib.smh_model_forward_x0_bf16(
                 self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()), 1,
-                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_bf16")
+                _lib.current_stream()), "smh_model_forward_x0_bf16")
             return out
         if dtype != "f32":
             raise ValueError("dtype must be 'f32' or 'bf16' (split bf16 operands), got %r" % (dtype,))
         _lib.check(self.lib.smh_model_forward_x0_f32(
             self._h, C.c_void_p(x0p.data_ptr()), N, C.c_void_p(out.data_ptr()),
             None if trunk is None else C.c_void_p(trunk.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_x0_f32")
+            _lib.current_stream()), "smh_model_forward_x0_f32")
         return out
 
     def forward_dense(self, fv, shift=1, out=None):
@@ -295,7 +295,7 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         work = torch.empty((nbytes // 4,), dtype=torch.float32, device=fv.device)
         got = _lib.check(self.lib.smh_model_forward_dense_f32(
             self._h, C.c_void_p(fv.data_ptr()), Tc, int(shift), C.c_void_p(work.data_ptr()), nbytes, C.c_void_p(out.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_forward_dense_f32")
+            _lib.current_stream()), "smh_model_forward_dense_f32")
         if got != nP:
             raise RuntimeError("smh_model_forward_dense_f32 produced %d patches, expected %d" % (got, nP))
         return out
@@ -324,4 +324,4 @@ class B3MTL(TrainingMixin, ModelSurfaceMixin):
         """Wait for the current stream and raise RuntimeError if a forward kernel recorded in the model's device error word
         that its outputs are not results (include/smh.h: smh_model_status).  `forward_device` / `forward_from_x0` only enqueue
         work; callers that keep results on the device call this before trusting them (`predict` and bench.py do)."""
-        _lib.check(self.lib.smh_model_status(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "smh_model_status")
+        _lib.check(self.lib.smh_model_status(self._h, _lib.current_stream()), "smh_model_status")

@@ -70,7 +70,7 @@ class HotPath:
         if audio.shape != (self.B, self.n_samples) or audio.dtype != torch.float32 or not audio.is_cuda:
             raise ValueError("audio must be a float32 device tensor of shape (%d, %d)" % (self.B, self.n_samples))
         lib, h, fe, m = self.lib, self._h, self.fe, self.model
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = _lib.current_stream()
         if m is not None:
             m._sync_weights()
         if record is not None:

@@ -47,7 +47,7 @@ _LOSS_OF = {"S": "binary_crossentropy", "M": "binary_crossentropy", "N": "binary
 
 
 def _cur_stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream()
 
 
 def process_group():
