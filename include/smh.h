@@ -154,7 +154,10 @@ int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samp
  * clip takes the same kernels as in smh_frontend_f32 and gets the same bits).  Consecutive clips of equal length lying back
  * to back are batched into one launch set.  Outputs are concatenated: clip b's featuregram (2*rows, T_b) starts at float
  * h_fv_off[b] of d_fv, its nP_b standardised time-major patches at patch h_patch_off[b] of d_patches ((W, 2*rows) each).
- * smh_frontend_ragged_sizes fills the per-clip tables (each may be NULL) and the workspace requirement; W <= 0: no patches. */
+ * smh_frontend_ragged_sizes fills the per-clip tables (each may be NULL) and the workspace requirement; W <= 0: no patches.
+ * The clips' dependent kernel chains are spread over up to four streams of the library's own, forked from `stream` at entry and joined
+ * back into it at exit (the call is stream-ordered for the caller like every other entry point); the workspace requirement is one
+ * slice per such lane, a smaller workspace gives fewer lanes (at least one slice: the largest launch set's smh_frontend_workspace_bytes). */
 int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_offsets, const int *h_lengths, int B, int W, int shift,
                               long long *h_fv_off /* B+1 */, long long *h_patch_off /* B+1 */, int *h_T /* B */,
                               int *h_nP /* B */, size_t *work_bytes);

@@ -171,6 +171,44 @@ int plan_ragged(const smh_ctx *ctx, const long long *off, const int *len, int B,
     }
     return SMH_OK;
 }
+// Lanes of a ragged call: a file's kernels form a dependent chain of small (B = 1) launches that leaves most of the chip idle, and
+// the chains of different files have nothing to do with each other -- so consecutive launch sets go round-robin to kRaggedLanes
+// streams of the library's own (forked from the caller's stream by an event at entry, joined back into it by one event per lane
+// at exit: the call stays stream-ordered for the caller, and capturable), each with its own slice of the workspace.
+// SMH_RAGGED_STREAMS=1 runs everything on the caller's stream as before.
+constexpr int kRaggedLanes = 16;  // upper bound; ragged_lanes() is what a call uses
+constexpr int kRaggedDefault = 16;  // 1 / 2 / 4 / 8 / 16 lanes, 256 files of 1-10 s: 21.1 / 11.9 / 12.9 / 9.6 / 8.0 ms per call (profiles/r03_ragged.txt)
+constexpr size_t kRaggedWorkCap = (size_t)4 << 30;  // ... but no more lanes than slices fit in 4 GiB (hour-long files: one lane)
+int ragged_lanes() {
+    int n = kRaggedDefault;
+    if (const char *ev = getenv("SMH_RAGGED_STREAMS")) n = std::max(1, std::min(atoi(ev), kRaggedLanes));
+    return n;
+}
+struct LanePool {
+    hipStream_t st[kRaggedLanes] = {};
+    hipEvent_t fork = nullptr, join[kRaggedLanes] = {};
+    int device = -1;
+};
+// one pool per host thread and device (a call forks and joins inside itself: pools are never shared between concurrent calls)
+constexpr int kMaxDevices = 16;
+int lane_pool(LanePool **out) {
+    thread_local LanePool pools[kMaxDevices];
+    int dev = 0;
+    SMH_CHECK_HIP(hipGetDevice(&dev));
+    SMH_REQUIRE(dev >= 0 && dev < kMaxDevices, "smh_frontend_ragged_f32: device index %d", dev);
+    LanePool &pool = pools[dev];
+    if (pool.device != dev) {
+        for (int i = 0; i < kRaggedLanes; ++i) {
+            SMH_CHECK_HIP(hipStreamCreateWithFlags(&pool.st[i], hipStreamNonBlocking));
+            SMH_CHECK_HIP(hipEventCreateWithFlags(&pool.join[i], hipEventDisableTiming));
+        }
+        SMH_CHECK_HIP(hipEventCreateWithFlags(&pool.fork, hipEventDisableTiming));
+        pool.device = dev;
+    }
+    *out = &pool;
+    return SMH_OK;
+}
+
 // clips b .. e-1 form one launch set: same length, back to back
 int run_end(const long long *off, const int *len, int B, int b) {
     int e = b + 1;
@@ -201,7 +239,12 @@ extern "C" int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_
         if (h_T) h_T[b] = p.T[b];
         if (h_nP) h_nP[b] = p.nP[b];
     }
-    if (work_bytes) *work_bytes = work;
+    if (work_bytes) {  // one slice per lane (see ragged_lanes), within kRaggedWorkCap
+        const size_t slice = align_up(work, 256);
+        size_t lanes = (size_t)ragged_lanes();
+        if (slice) lanes = std::max<size_t>(1, std::min(lanes, kRaggedWorkCap / slice));
+        *work_bytes = slice * lanes;
+    }
     return SMH_OK;
 }
 
@@ -215,13 +258,44 @@ extern "C" int smh_frontend_ragged_f32(const smh_ctx *ctx, const float *d_audio,
     int rc = plan_ragged(ctx, h_offsets, h_lengths, B, W, shift, patches, p);
     if (rc) return rc;
     const size_t prow = (size_t)W * 2 * ctx->feat_rows;
-    for (int b = 0; b < B;) {
+    // workspace of the largest launch set = one slice; as many lanes as whole slices fit (ragged_sizes asks for ragged_lanes() of them)
+    size_t slice = 0;
+    int n_sets = 0;
+    for (int b = 0; b < B; ++n_sets) {
         const int e = run_end(h_offsets, h_lengths, B, b);
-        float *pt = patches && p.nP[b] > 0 ? d_patches + (size_t)p.patch_off[b] * prow : nullptr;
-        rc = smh_frontend_f32(ctx, d_audio + h_offsets[b], e - b, h_lengths[b], pt ? W : 0, pt ? shift : 0, d_fv + p.fv_off[b], pt,
-                              d_work, work_bytes, nullptr, nullptr, nullptr, stream);
-        if (rc < 0) return rc;
+        slice = std::max(slice, smh_frontend_workspace_bytes(ctx, e - b, h_lengths[b]));
         b = e;
     }
-    return SMH_OK;
+    slice = align_up(slice, 256);
+    int lanes = slice ? (int)std::min<size_t>((size_t)ragged_lanes(), work_bytes / slice) : 1;
+    if (lanes > n_sets) lanes = n_sets;
+    if (lanes < 1) lanes = 1;  // (a workspace below one slice is reported by smh_frontend_f32)
+    hipStream_t caller = (hipStream_t)stream;
+    LanePool *pool = nullptr;
+    if (lanes > 1) {
+        rc = lane_pool(&pool);
+        if (rc) return rc;
+        SMH_CHECK_HIP(hipEventRecord(pool->fork, caller));
+        for (int i = 0; i < lanes; ++i) SMH_CHECK_HIP(hipStreamWaitEvent(pool->st[i], pool->fork, 0));
+    }
+    int set = 0, err = SMH_OK;
+    for (int b = 0; b < B; ++set) {
+        const int e = run_end(h_offsets, h_lengths, B, b);
+        float *pt = patches && p.nP[b] > 0 ? d_patches + (size_t)p.patch_off[b] * prow : nullptr;
+        const int lane = lanes > 1 ? set % lanes : 0;
+        rc = smh_frontend_f32(ctx, d_audio + h_offsets[b], e - b, h_lengths[b], pt ? W : 0, pt ? shift : 0, d_fv + p.fv_off[b], pt,
+                              (char *)d_work + (lanes > 1 ? (size_t)lane * slice : 0), lanes > 1 ? slice : work_bytes, nullptr, nullptr,
+                              nullptr, lanes > 1 ? (void *)pool->st[lane] : stream);
+        if (rc < 0) {
+            err = rc;
+            break;
+        }
+        b = e;
+    }
+    if (lanes > 1)  // join also on an error: the caller's stream must not run ahead of what was enqueued
+        for (int i = 0; i < lanes; ++i) {
+            SMH_CHECK_HIP(hipEventRecord(pool->join[i], pool->st[i]));
+            SMH_CHECK_HIP(hipStreamWaitEvent(caller, pool->join[i], 0));
+        }
+    return err;
 }

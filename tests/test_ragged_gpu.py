@@ -50,6 +50,29 @@ def test_ragged_equals_per_clip_and_equal_length_batches_bit_for_bit(fe):
         fe.run_ragged([clips[0], clips[0][:300]], W=68, shift=34)  # shorter than n_fft
 
 
+def test_ragged_lanes_give_the_same_bits_as_one_stream(fe, monkeypatch):
+    """smh_frontend_ragged_f32 spreads the files' kernel chains over streams of its own (forked from / joined into the caller's stream)
+    with a workspace slice each: same featuregrams and patches, bit for bit, as everything on the caller's stream
+    (SMH_RAGGED_STREAMS=1); and the call is stream-ordered -- results read on the caller's stream right behind it are complete."""
+    from sm_hpss_mtl_amd.synth import synth_clips
+    rng = np.random.default_rng(2)
+    lens = [int(rng.integers(6000, 70000)) // 2 * 2 for _ in range(23)]
+    clips = [synth_clips(1, seed=300 + i, n_samples=n)[0] for i, n in enumerate(lens)]
+    monkeypatch.setenv("SMH_RAGGED_STREAMS", "1")
+    one = fe.run_ragged(clips, W=68, shift=34)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("SMH_RAGGED_STREAMS")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # not the default stream: the fork / join must follow the CALLER's stream
+        many = fe.run_ragged(clips, W=68, shift=34)
+        sums = [float(t.sum()) for t in many["fv"]]  # consumed on the caller's stream right behind the call
+    torch.cuda.synchronize()
+    assert many["T"] == one["T"] and many["n_patches"] == one["n_patches"]
+    for i in range(len(clips)):
+        assert torch.equal(many["fv"][i], one["fv"][i]) and torch.equal(many["patches"][i], one["patches"][i]), i
+        assert sums[i] == float(one["fv"][i].sum())
+
+
 def _params(tmp, sub):
     m = "Lemaire_et_al_MTL"
     return {"Model": m, "classes": {0: "music", 1: "speech", 2: "speech_music"}, "feature_opDir": str(tmp / sub), "W": 68, "W_shift": 24,
