@@ -18,3 +18,9 @@ run feat_two_kernels SMH_FEAT_TWO_KERNELS=1
 run median_nosplit SMH_MEDIAN_NOSPLIT=1
 run median_persist SMH_MEDIAN_PERSIST=1
 run feat_taps SMH_FEAT_TAPS=1
+if [ "$1" = all ]; then
+run feat_w0lds SMH_FEAT_W0LDS=1
+run stft_plain_grid SMH_STFT_XCD=0
+run ragged_one_stream SMH_RAGGED_STREAMS=1
+run dense_patches SMH_DENSE_PATCHES=1
+fi
