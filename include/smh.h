@@ -120,7 +120,7 @@ int smh_extract_patches_f32(const smh_ctx *ctx, const float *d_FV, int B, int F,
 
 /* Layouts of the harmonic median between smh_hpss_median_ex_f32 and the feature stage (harm_layout):
  *   0 = (B, K, T) as the reference returns it, 1 = (B, T, K), 2 = (B, ceil(T/16), K, 16) -- 16-frame blocks, written
- *   by the block-split median kernels (windows <= 21, whole clip in one tile) and read by the single-kernel feature
+ *   by the block-split median kernels (windows <= 21; any clip length, tile by tile) and read by the single-kernel feature
  *   path.  A harm buffer of smh_harm_buffer_floats(K, T) floats per clip has room for every layout;
  *   smh_features_blocked_ok tells whether the feature stage accepts layout 2 for clips of T frames (with_l0: together
  *   with the layer-0 fusion of smh_features_l0_f32).  smh_hpss_median_ex_f32 returns the layout it actually wrote.  */

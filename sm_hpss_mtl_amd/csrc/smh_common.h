@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "../../include/smh.h"
@@ -41,6 +42,11 @@ constexpr int kLdsBytesPerCU = 160 * 1024;
 
 }  // namespace smh
 
+namespace smh_rag {
+struct Staging;  // pinned host buffers of the ragged calls' descriptor uploads (smh_ragged.hip)
+void destroy_staging(Staging *);
+}  // namespace smh_rag
+
 // Front-end context: immutable device tables + the config they were built for.
 struct smh_ctx {
     smh_frontend_cfg cfg;
@@ -74,4 +80,7 @@ struct smh_ctx {
         feat_off[2][kMaxFeatSegs];
     float *d_feat_plan;
     std::vector<float> h_mel_dense;  // (n_mels, K) host copy
+    // the one mutable part: staging buffers for the descriptor tables of ragged calls, created on first use, guarded by rag_mu
+    mutable smh_rag::Staging *rag_staging = nullptr;
+    mutable std::mutex rag_mu;
 };

@@ -286,6 +286,7 @@ extern "C" void smh_ctx_destroy(smh_ctx *c) {
     (void)hipFree(c->d_mel_count);
     (void)hipFree(c->d_mel_off);
     (void)hipFree(c->d_mel_w);
+    smh_rag::destroy_staging(c->rag_staging);
     delete c;
 }
 

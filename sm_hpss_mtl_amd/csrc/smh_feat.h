@@ -15,6 +15,17 @@ struct MelTable {
 
 MelTable mel_table(const smh_ctx *c);
 
+// the bin walk's per-context plan as a kernel argument (smh_ctx.hip builds it): row segments, their bin ranges, and where each
+// segment's per-bin records {w0, w1, w2, w3, n_emit, -, -, -} start in `plan`
+struct FeatPlan {
+    int nseg, pend;  // pend: most filters pending at any bin (2 or 4 accumulators)
+    int m0[smh_ctx::kMaxFeatSegs], m1[smh_ctx::kMaxFeatSegs], kbeg[smh_ctx::kMaxFeatSegs], kend[smh_ctx::kMaxFeatSegs],
+        off[smh_ctx::kMaxFeatSegs];
+    const float *plan;
+    unsigned long long *trace;  // tools/trace_features.py: phase stamps (s_memrealtime) per workgroup and wave, or nullptr
+};
+FeatPlan feat_plan(const smh_ctx *c, int which /* 0: four segments, 1: eight */);
+
 // (S, harm, perc) -> featuregram fv (B, 2*rows, T) with un-clipped dB values + per-array max keys
 // harm_tmajor != 0: harm is (B, T, K) as written by smh_median::launch_hpss(want_tmajor = 1)
 int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const float *perc, int harm_tmajor, int B, int T,

@@ -8,6 +8,7 @@
 
 #include "smh_common.h"
 #include "smh_feat.h"
+#include "smh_rag.h"
 
 namespace {
 
@@ -304,13 +305,7 @@ hp_feat_kernel(smh_feat::MelTable mel, int log_db, const float *__restrict__ S, 
 // vector loads of S and perc -- nothing in the loop depends on a table lookup.  S and perc rows are read coalesced
 // along frames, every element once; the time-major harm clip is copied to LDS (odd row stride) and read column-wise.
 // ---------------------------------------------------------------------------------------------------
-struct FeatPlan {
-    int nseg, pend;  // pend: most filters pending at any bin (2 or 4 accumulators)
-    int m0[smh_ctx::kMaxFeatSegs], m1[smh_ctx::kMaxFeatSegs], kbeg[smh_ctx::kMaxFeatSegs], kend[smh_ctx::kMaxFeatSegs],
-        off[smh_ctx::kMaxFeatSegs];
-    const float *plan;
-    unsigned long long *trace;  // tools/trace_features.py: phase stamps (s_memrealtime) per workgroup and wave, or nullptr
-};
+using smh_feat::FeatPlan;
 constexpr int kWalkBatch = 8;  // bins of loads in flight per lane
 constexpr int kHalfBatch = 8;   // the same in features_half_kernel (lane = frame pair)
 constexpr int kL0Steps = 30;    // k steps of the layer-0 products (four rows each) that features_half_kernel's per-M-tile form is built for: 120 mel rows
@@ -564,23 +559,33 @@ __global__ void clip_fv_kernel(float *__restrict__ fv, const int *__restrict__ m
 // HBM traffic per clip: S + harm + perc in, featuregram + layer-0 partials out = 360 KB instead of 566 KB.
 // LDS: image [2*rows][T|1] + 3 floats per row + 32 ints  (98 frames, 240 rows: 98 KB, one workgroup per CU).
 // ---------------------------------------------------------------------------------------------------
+// RAG (smh_rag.h): workgroup i takes clip list[i] of a ragged call -- T, the tiled length, the patch count and every buffer offset
+// come from that clip's descriptor; the arithmetic is the equal-length instantiation's, so a clip gets the same bits in both.
+template <bool RAG>
 __global__ void __launch_bounds__(1024)
 features_clip_kernel(FeatPlan fp, int log_db, int stop_after /* tuning: phase probe */, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
                      float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
-                     float *__restrict__ x0p) {
+                     float *__restrict__ x0p, const smh_rag::Clip *__restrict__ rag, const int *__restrict__ list) {
     extern __shared__ __attribute__((aligned(16))) float img[];  // [R2][ld]
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int b = blockIdx.x;
+    size_t cb, hb, fvb, pb;  // this clip's S / perc, blocked harm, featuregram (floats) and first patch
+    if constexpr (RAG) {
+        const smh_rag::Clip &c = rag[list[b]];
+        T = c.T, Ttiled = c.Ttiled, nP = c.nP;
+        cb = (size_t)c.spec_off, hb = (size_t)c.harm_off, fvb = (size_t)c.fv_off, pb = (size_t)c.patch_off;
+    } else {
+        cb = (size_t)b * K * T, hb = (size_t)b * ((T + 15) >> 4) * K * 16, fvb = (size_t)b * 2 * rows * T, pb = (size_t)b * nP;
+    }
     const int ld = T | 1, R2 = 2 * rows;
     float *s_mean = img + (size_t)R2 * ld;  // mean hi [R2], 1/scale [R2], mean lo [R2]
     float *s_inv = s_mean + R2, *s_lo = s_mean + 2 * R2;
     int *smax = reinterpret_cast<int *>(s_mean + 3 * (size_t)R2);  // 32 ints
     float *w0s = s_mean + 3 * (size_t)R2 + 32;  // layer-0 weights [R2][32] (x0p only)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    const size_t cb = (size_t)b * K * T;
-    const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
+    const float *hclip = harmb + hb;
     float mxH = 0.f, mxP = 0.f;  // maxima of the filter sums (sums of non-negative terms)
 
     // ---- the bin walk, lane = frame (odd T) ----
@@ -660,7 +665,7 @@ features_clip_kernel(FeatPlan fp, int log_db, int stop_after /* tuning: phase pr
     }
     // dB + clip in LDS (the image becomes the final featuregram), write it out (coalesced rows)
     auto final_value = [&](float x, float lim) { return log_db ? 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(x * x, lim)) : x; };
-    float *g = fv + (size_t)b * R2 * T;
+    float *g = fv + fvb;
     if ((T & 1) == 0) {  // rows start on 8-byte boundaries: one float2 per lane, a 98-frame row is one instruction
         for (int r = wave; r < R2; r += nw) {
             const float lim = r < rows ? limH : limP;
@@ -763,7 +768,7 @@ features_clip_kernel(FeatPlan fp, int log_db, int stop_after /* tuning: phase pr
             }
             c0a += c0b, c1a += c1b;
             if (jt < W) {
-                float *o = x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q;
+                float *o = x0p + (((pb + p) * 2 + half) * W + jt) * 32 + 4 * q;
                 *reinterpret_cast<f32x4 *>(o) = c0a;
                 *reinterpret_cast<f32x4 *>(o + 16) = c1a;
             }
@@ -774,7 +779,7 @@ features_clip_kernel(FeatPlan fp, int log_db, int stop_after /* tuning: phase pr
         int s0 = p * shift;
         const int e = min(s0 + W, Ttiled);
         if (e - s0 < W) s0 = e - W;
-        float *o = patches + ((size_t)b * nP + p) * W * R2;
+        float *o = patches + (pb + p) * W * R2;
         for (int j = wave; j < W; j += nw) {  // one wave per frame: lanes over the 2*rows features (960-byte rows)
             int tt = s0 + j;
             tt -= (tt / T) * T;
@@ -815,12 +820,14 @@ __global__ void fill_int_kernel(int *p, int n, int v) {
 // TRACE: tools/trace_features.py only.  The stamps cost registers (93 instead of 78, i.e. the third workgroup per CU); the
 // TRACE build is therefore held to 80 VGPRs and spills ten of them: its timeline is indicative, not the plain build's.
 // PROBE: tools/perc_in_walk_bound.py only (SMH_FEAT_PROBE_PERC): a separate instantiation, the plain kernel's registers stay as they are
-template <int NP, bool TRACE = false, bool PROBE = false>
+// RAG (smh_rag.h): the B entries of `list` are clips of a ragged call (all of even T); T, the tiled length, the patch count and every
+// buffer offset come from the clip's descriptor; the arithmetic is the equal-length instantiation's, so a clip gets the same bits.
+template <int NP, bool TRACE = false, bool PROBE = false, bool RAG = false>
 __global__ void __launch_bounds__(512, (TRACE ? 6 : 1))
 features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__restrict__ S, const float *__restrict__ harmb,
                      const float *__restrict__ perc, int B, int K, int T, int rows, int Ttiled, int W, int shift, int nP,
                      float *__restrict__ fv, float *__restrict__ patches, const float *__restrict__ w0,
-                     float *__restrict__ x0p) {
+                     float *__restrict__ x0p, const smh_rag::Clip *__restrict__ rag, const int *__restrict__ list) {
     extern __shared__ __attribute__((aligned(16))) float img[];  // [rows][ld]
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -828,6 +835,14 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
     const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
     const int half = rr >> 3, b = grp * 8 + (rr & 7);
     if (b >= B) return;
+    size_t cb, hb, fvb, pb;  // this clip's S / perc, blocked harm, featuregram (floats) and first patch
+    if constexpr (RAG) {
+        const smh_rag::Clip &c = rag[list[b]];
+        T = c.T, Ttiled = c.Ttiled, nP = c.nP;
+        cb = (size_t)c.spec_off, hb = (size_t)c.harm_off, fvb = (size_t)c.fv_off, pb = (size_t)c.patch_off;
+    } else {
+        cb = (size_t)b * K * T, hb = (size_t)b * ((T + 15) >> 4) * K * 16, fvb = (size_t)b * 2 * rows * T, pb = (size_t)b * nP;
+    }
     const bool w0_lds = !(stop_after & 16);  // bit 4 of the probe argument: layer-0 weights from L2 instead of an LDS copy
     // bits 8..15 (timing probe SMH_FEAT_PROBE_PERC = n, outputs invalid): what "the percussive median inside this walk" would
     // cost -- perc is NOT read (S stands in for it), every bin step issues 2 n selection instructions (n per frame of the lane's
@@ -854,8 +869,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         }
     };
     stamp(0);
-    const size_t cb = (size_t)b * K * T;
-    const float *hclip = harmb + (size_t)b * ((T + 15) >> 4) * K * 16;
+    const float *hclip = harmb + hb;
     float mx = 0.f;  // maximum of this half's filter sums (sums of non-negative terms)
 
     const int npair = T >> 1;
@@ -969,7 +983,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         }
     }
     // dB + clip in LDS (the image becomes this half of the final featuregram), write it out (coalesced rows)
-    float *g = fv + ((size_t)b * R2 + (size_t)half * rows) * T;
+    float *g = fv + fvb + (size_t)half * rows * T;
     for (int r = wave; r < rows; r += nw) {
         for (int t2 = lane; t2 < T / 2; t2 += 64) {
             float x0 = img[r * ld + 2 * t2], x1 = img[r * ld + 2 * t2 + 1];
@@ -1067,7 +1081,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             }
             c0a += c0b, c1a += c1b;
             if (jt < W) {
-                float *o = x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q;
+                float *o = x0p + (((pb + p) * 2 + half) * W + jt) * 32 + 4 * q;
                 *reinterpret_cast<f32x4 *>(o) = c0a;
                 *reinterpret_cast<f32x4 *>(o + 16) = c1a;
             }
@@ -1119,7 +1133,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
             }
             ca += cb;
             if (jt < W)
-                *reinterpret_cast<f32x4 *>(x0p + ((((size_t)b * nP + p) * 2 + half) * W + jt) * 32 + 4 * q + 16 * mt) = ca;
+                *reinterpret_cast<f32x4 *>(x0p + (((pb + p) * 2 + half) * W + jt) * 32 + 4 * q + 16 * mt) = ca;
         }
     };
     if (x0p) {
@@ -1133,7 +1147,7 @@ features_half_kernel(FeatPlan fp, int log_db, int stop_after, const float *__res
         int s0 = p * shift;
         const int e = min(s0 + W, Ttiled);
         if (e - s0 < W) s0 = e - W;
-        float *o = patches + ((size_t)b * nP + p) * W * R2 + (size_t)half * rows;
+        float *o = patches + (pb + p) * W * R2 + (size_t)half * rows;
         for (int j = wave; j < W; j += nw) {  // one wave per frame: lanes over this half's features
             int tt = s0 + j;
             tt -= (tt / T) * T;
@@ -1180,6 +1194,17 @@ extern "C" int smh_internal_feat_residency(int rows, int T) {
 
 namespace smh_feat {
 
+FeatPlan feat_plan(const smh_ctx *c, int which) {
+    FeatPlan fp;
+    fp.nseg = c->feat_nseg[which], fp.pend = c->feat_pend;
+    for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
+        fp.m0[i] = c->feat_m0[which][i], fp.m1[i] = c->feat_m1[which][i], fp.kbeg[i] = c->feat_kbeg[which][i],
+        fp.kend[i] = c->feat_kend[which][i], fp.off[i] = c->feat_off[which][i];
+    fp.plan = c->d_feat_plan;
+    fp.trace = nullptr;
+    return fp;
+}
+
 MelTable mel_table(const smh_ctx *c) {
     MelTable m;
     m.n_mels = c->n_mels;
@@ -1202,13 +1227,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     const size_t lds_walk = sizeof(float) * (harm_tmajor ? (size_t)T * (K | 1) : 0) + 128;
     const int walk_waves = c->feat_nseg[0] * ((T + 63) / 64);
     if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !getenv("SMH_FEAT_TAPS")) {
-        FeatPlan fp;
-        fp.nseg = c->feat_nseg[0], fp.pend = c->feat_pend;
-        for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
-            fp.m0[i] = c->feat_m0[0][i], fp.m1[i] = c->feat_m1[0][i], fp.kbeg[i] = c->feat_kbeg[0][i],
-            fp.kend[i] = c->feat_kend[0][i], fp.off[i] = c->feat_off[0][i];
-        fp.plan = c->d_feat_plan;
-        fp.trace = nullptr;
+        const FeatPlan fp = feat_plan(c, 0);
         const int nwaves = std::min(16, walk_waves);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
         hipLaunchKernelGGL(hp_feat_walk_kernel, dim3(B), dim3(64 * nwaves), lds_walk, st, fp, c->cfg.log_db, S, harm, perc,
@@ -1237,12 +1256,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
     if (lds > 158 * 1024) return 0;
     // even T: one workgroup per (clip, half), lane = frame pair (features_half_kernel); odd T: one workgroup per clip, lane = frame
     const int pair = (T % 2 == 0 && !getenv("SMH_FEAT_NOPAIR")) ? 1 : 0;
-    FeatPlan fp;
-    fp.nseg = c->feat_nseg[1], fp.pend = c->feat_pend;
-    for (int i = 0; i < smh_ctx::kMaxFeatSegs; ++i)
-        fp.m0[i] = c->feat_m0[1][i], fp.m1[i] = c->feat_m1[1][i], fp.kbeg[i] = c->feat_kbeg[1][i],
-        fp.kend[i] = c->feat_kend[1][i], fp.off[i] = c->feat_off[1][i];
-    fp.plan = c->d_feat_plan;
+    FeatPlan fp = feat_plan(c, 1);
     fp.trace = g_feat_trace;
     const char *stop_ev = smh::probe_env("SMH_FEAT_STOP");  // timing probe: the kernel returns early
     int stop = stop_ev ? atoi(stop_ev) & 15 : 0;
@@ -1275,7 +1289,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<NPV, TR, ##__VA_ARGS__>,                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));                      \
         hipLaunchKernelGGL((features_half_kernel<NPV, TR, ##__VA_ARGS__>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S, \
-                           harmb, perc, B, K, T, rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);     \
+                           harmb, perc, B, K, T, rows, smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p, nullptr, nullptr); \
     } while (0)
         if (probe >> 8) {  // SMH_FEAT_PROBE_PERC: the instantiation with the probe compiled in (outputs invalid)
             SMH_LAUNCH_HALF(2, false, true);
@@ -1290,11 +1304,41 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         int rch = smh::launch_status("features_half_kernel");
         return rch ? rch : 1;
     }
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(features_clip_kernel, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, K, T, rows,
-                       smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p);
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(features_clip_kernel<false>, dim3(B), dim3(1024), lds, st, fp, c->cfg.log_db, stop & 15, S, harmb, perc, K, T, rows,
+                       smh_tiled_frames(T, W), W, shift, nP, fv, patches, w0, x0p, nullptr, nullptr);
     int rc = smh::launch_status("features_clip_kernel");
     return rc ? rc : 1;
+}
+
+// Clips of different lengths that each fit the LDS image (smh_rag.h): the same two kernels, one workgroup (pair) per list entry.
+int launch_features_rag(const smh_ctx *c, const float *S, const float *harmb, const float *perc, const smh_rag::Clip *d_clips,
+                        const int *d_list, int n, int max_T, int even_T, int W, int shift, float *fv, float *patches, hipStream_t st) {
+    if (n <= 0) return SMH_OK;
+    const int K = c->K, rows = c->feat_rows;
+    const FeatPlan fp = feat_plan(c, 1);
+    if (even_T) {
+        const size_t ldh = sizeof(float) * ((size_t)rows * (max_T | 1) + 3 * (size_t)rows) + 64;
+        const unsigned grid = 16u * (unsigned)((n + 7) / 8);
+        const int probe = 16;  // (layer-0 weights are not used here)
+        if (fp.pend <= 2) {
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<2, false, false, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
+            hipLaunchKernelGGL((features_half_kernel<2, false, false, true>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S,
+                               harmb, perc, n, K, 0, rows, 0, W, shift, 0, fv, patches, nullptr, nullptr, d_clips, d_list);
+        } else {
+            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_half_kernel<4, false, false, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh));
+            hipLaunchKernelGGL((features_half_kernel<4, false, false, true>), dim3(grid), dim3(512), ldh, st, fp, c->cfg.log_db, probe, S,
+                               harmb, perc, n, K, 0, rows, 0, W, shift, 0, fv, patches, nullptr, nullptr, d_clips, d_list);
+        }
+        return smh::launch_status("features_half_kernel (ragged)");
+    }
+    const size_t lds = sizeof(float) * ((size_t)2 * rows * (max_T | 1) + 3 * (size_t)2 * rows) + 128;
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)features_clip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(features_clip_kernel<true>, dim3(n), dim3(1024), lds, st, fp, c->cfg.log_db, 0, S, harmb, perc, K, 0, rows, 0, W,
+                       shift, 0, fv, patches, nullptr, nullptr, d_clips, d_list);
+    return smh::launch_status("features_clip_kernel (ragged)");
 }
 
 int launch_std_patch(const smh_ctx *c, float *fv, const int *maxkeys, int B, int T, int W, int shift, int nP,

@@ -9,10 +9,17 @@
 
 #include "smh_common.h"
 #include "smh_feat.h"
+#include "smh_rag.h"
 
 namespace {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 }  // namespace
+
+namespace smh_rag {  // smh_ragged.hip: the streaming kernels that serve clips beyond the LDS image
+size_t equal_overhead_bytes(const smh_ctx *ctx, int B, int T);
+int run_equal(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, int T, int W, int shift, int nP, float *d_fv,
+              float *d_patches, void *d_work, size_t work_bytes, bool stft_aligned8, hipStream_t st);
+}  // namespace smh_rag
 
 extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const float *d_harm, const float *d_perc,
                                    int harm_layout, int B, int T, int W, int shift, float *d_fv, float *d_patches,
@@ -93,7 +100,11 @@ extern "C" size_t smh_frontend_workspace_bytes(const smh_ctx *ctx, int B, int n_
     if (T < 1) return 0;
     const size_t spec = align_up((size_t)B * ctx->K * T * sizeof(float), 256);
     const size_t hspec = align_up((size_t)B * smh_harm_buffer_floats(ctx->K, T) * sizeof(float), 256);
-    return 2 * spec + hspec + align_up((size_t)2 * B * sizeof(int), 256);
+    size_t total = 2 * spec + hspec + align_up((size_t)2 * B * sizeof(int), 256);
+    // clips beyond the LDS image take the length-array kernels of smh_ragged.hip: their tables and row statistics, and S / perc
+    // clip by clip on 16-byte boundaries
+    if (!smh_features_blocked_ok(ctx, T, 0)) total += smh_rag::equal_overhead_bytes(ctx, B, T) + (size_t)B * 32;
+    return total;
 }
 
 extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, int W, int shift,
@@ -120,7 +131,17 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
     }
     if (B == 0) return nP;
     hipStream_t st = (hipStream_t)stream;
-    int rc = smh_stft_mag_f32(ctx, d_audio, B, n_samples, S, stream);
+    int rc;
+    if (!d_S && !d_harm && !d_perc && !smh_features_blocked_ok(ctx, T, 0)) {
+        // Clips beyond the LDS image (longer than ~1.6 s at 240 rows), no taps: the streaming kernels of the ragged front end, fed the
+        // tables of B equal clips -- a file gets the same bits alone, in an equal-length batch and in a ragged one.  The STFT kernel is
+        // the one smh_stft_mag_f32 would pick for this batch.
+        const bool aligned8 = ((n_samples % 2) == 0 || B == 1) && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0;
+        rc = smh_rag::run_equal(ctx, d_audio, B, n_samples, T, W, shift, nP, d_fv, nP > 0 ? d_patches : nullptr, d_work, work_bytes, aligned8, st);
+        if (rc < 0) return rc;
+        if (rc == 1) return nP;
+    }
+    rc = smh_stft_mag_f32(ctx, d_audio, B, n_samples, S, stream);
     if (rc) return rc;
     // the harmonic median is written time-major (coalesced stores) unless the caller taps it
     // the harmonic median is written in the layout its consumer reads best unless the caller taps it:
@@ -143,159 +164,4 @@ extern "C" int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B,
                                     nP > 0 ? d_patches : nullptr, st, nullptr, nullptr, (d_S || d_perc) ? nullptr : w, 2 * spec);
     if (rc) return rc;
     return nP;
-}
-
-// ---- ragged batches: clips of different lengths in one call (the reference's generators process whole files of any length
-// one by one: Proposed_Work_Results.py:92-95, 131-134, 189-192, 465-474) -------------------------------------------------------
-// Host-side orchestration over the batched kernels above: consecutive clips of the same length that lie back to back in the
-// audio buffer are one launch set, every other clip is a launch set of its own, all on the caller's stream.  Kernel choice
-// depends on (length, pointer alignment) exactly as for smh_frontend_f32, so with 8-byte aligned clip starts every clip gets
-// bit for bit what smh_frontend_f32 gives it alone or inside an equal-length batch.
-namespace {
-struct RaggedPlan {
-    std::vector<int> T, nP;
-    std::vector<long long> fv_off, patch_off;  // floats / patches in front of clip b
-    size_t work = 0;
-};
-int plan_ragged(const smh_ctx *ctx, const long long *off, const int *len, int B, int W, int shift, bool patches, RaggedPlan &p) {
-    p.T.assign(B, 0), p.nP.assign(B, 0), p.fv_off.assign(B + 1, 0), p.patch_off.assign(B + 1, 0);
-    const int rows2 = 2 * ctx->feat_rows;
-    for (int b = 0; b < B; ++b) {
-        SMH_REQUIRE(off[b] >= 0 && len[b] >= 0, "ragged: clip %d has a negative offset or length", b);
-        const int T = smh_num_frames(len[b], ctx->cfg.n_fft, ctx->cfg.hop);
-        SMH_REQUIRE(T >= 1, "ragged: clip %d of %d samples is shorter than n_fft=%d", b, len[b], ctx->cfg.n_fft);
-        p.T[b] = T;
-        p.nP[b] = patches ? smh_num_patches(smh_tiled_frames(T, W), W, shift) : 0;
-        p.fv_off[b + 1] = p.fv_off[b] + (long long)rows2 * T;
-        p.patch_off[b + 1] = p.patch_off[b] + p.nP[b];
-    }
-    return SMH_OK;
-}
-// Lanes of a ragged call: a file's kernels form a dependent chain of small (B = 1) launches that leaves most of the chip idle, and
-// the chains of different files have nothing to do with each other -- so consecutive launch sets go round-robin to kRaggedLanes
-// streams of the library's own (forked from the caller's stream by an event at entry, joined back into it by one event per lane
-// at exit: the call stays stream-ordered for the caller, and capturable), each with its own slice of the workspace.
-// SMH_RAGGED_STREAMS=1 runs everything on the caller's stream as before.
-constexpr int kRaggedLanes = 16;  // upper bound; ragged_lanes() is what a call uses
-constexpr int kRaggedDefault = 16;  // 1 / 2 / 4 / 8 / 16 lanes, 256 files of 1-10 s: 21.1 / 11.9 / 12.9 / 9.6 / 8.0 ms per call (profiles/r03_ragged.txt)
-constexpr size_t kRaggedWorkCap = (size_t)4 << 30;  // ... but no more lanes than slices fit in 4 GiB (hour-long files: one lane)
-int ragged_lanes() {
-    int n = kRaggedDefault;
-    if (const char *ev = getenv("SMH_RAGGED_STREAMS")) n = std::max(1, std::min(atoi(ev), kRaggedLanes));
-    return n;
-}
-struct LanePool {
-    hipStream_t st[kRaggedLanes] = {};
-    hipEvent_t fork = nullptr, join[kRaggedLanes] = {};
-    int device = -1;
-};
-// one pool per host thread and device (a call forks and joins inside itself: pools are never shared between concurrent calls)
-constexpr int kMaxDevices = 16;
-int lane_pool(LanePool **out) {
-    thread_local LanePool pools[kMaxDevices];
-    int dev = 0;
-    SMH_CHECK_HIP(hipGetDevice(&dev));
-    SMH_REQUIRE(dev >= 0 && dev < kMaxDevices, "smh_frontend_ragged_f32: device index %d", dev);
-    LanePool &pool = pools[dev];
-    if (pool.device != dev) {
-        for (int i = 0; i < kRaggedLanes; ++i) {
-            SMH_CHECK_HIP(hipStreamCreateWithFlags(&pool.st[i], hipStreamNonBlocking));
-            SMH_CHECK_HIP(hipEventCreateWithFlags(&pool.join[i], hipEventDisableTiming));
-        }
-        SMH_CHECK_HIP(hipEventCreateWithFlags(&pool.fork, hipEventDisableTiming));
-        pool.device = dev;
-    }
-    *out = &pool;
-    return SMH_OK;
-}
-
-// clips b .. e-1 form one launch set: same length, back to back
-int run_end(const long long *off, const int *len, int B, int b) {
-    int e = b + 1;
-    while (e < B && len[e] == len[b] && off[e] == off[e - 1] + len[b] && e - b < 65535) ++e;
-    return e;
-}
-}  // namespace
-
-extern "C" int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_offsets, const int *h_lengths, int B, int W,
-                                         int shift, long long *h_fv_off, long long *h_patch_off, int *h_T, int *h_nP,
-                                         size_t *work_bytes) {
-    SMH_REQUIRE(ctx && (B == 0 || (h_offsets && h_lengths)) && B >= 0, "smh_frontend_ragged_sizes: bad argument");
-    SMH_REQUIRE(W <= 0 || shift >= 1, "smh_frontend_ragged_sizes: bad patch geometry W=%d shift=%d", W, shift);
-    RaggedPlan p;
-    int rc = plan_ragged(ctx, h_offsets, h_lengths, B, W, shift, W > 0, p);
-    if (rc) return rc;
-    size_t work = 0;
-    for (int b = 0; b < B;) {
-        const int e = run_end(h_offsets, h_lengths, B, b);
-        work = std::max(work, smh_frontend_workspace_bytes(ctx, e - b, h_lengths[b]));
-        b = e;
-    }
-    for (int b = 0; b <= B; ++b) {
-        if (h_fv_off) h_fv_off[b] = p.fv_off[b];
-        if (h_patch_off) h_patch_off[b] = p.patch_off[b];
-    }
-    for (int b = 0; b < B; ++b) {
-        if (h_T) h_T[b] = p.T[b];
-        if (h_nP) h_nP[b] = p.nP[b];
-    }
-    if (work_bytes) {  // one slice per lane (see ragged_lanes), within kRaggedWorkCap
-        const size_t slice = align_up(work, 256);
-        size_t lanes = (size_t)ragged_lanes();
-        if (slice) lanes = std::max<size_t>(1, std::min(lanes, kRaggedWorkCap / slice));
-        *work_bytes = slice * lanes;
-    }
-    return SMH_OK;
-}
-
-extern "C" int smh_frontend_ragged_f32(const smh_ctx *ctx, const float *d_audio, const long long *h_offsets,
-                                       const int *h_lengths, int B, int W, int shift, float *d_fv, float *d_patches,
-                                       void *d_work, size_t work_bytes, void *stream) {
-    SMH_REQUIRE(ctx && d_audio && d_fv && d_work && h_offsets && h_lengths && B >= 0, "smh_frontend_ragged_f32: bad argument");
-    const bool patches = d_patches != nullptr;
-    SMH_REQUIRE(!patches || (W >= 1 && shift >= 1), "smh_frontend_ragged_f32: bad patch geometry W=%d shift=%d", W, shift);
-    RaggedPlan p;
-    int rc = plan_ragged(ctx, h_offsets, h_lengths, B, W, shift, patches, p);
-    if (rc) return rc;
-    const size_t prow = (size_t)W * 2 * ctx->feat_rows;
-    // workspace of the largest launch set = one slice; as many lanes as whole slices fit (ragged_sizes asks for ragged_lanes() of them)
-    size_t slice = 0;
-    int n_sets = 0;
-    for (int b = 0; b < B; ++n_sets) {
-        const int e = run_end(h_offsets, h_lengths, B, b);
-        slice = std::max(slice, smh_frontend_workspace_bytes(ctx, e - b, h_lengths[b]));
-        b = e;
-    }
-    slice = align_up(slice, 256);
-    int lanes = slice ? (int)std::min<size_t>((size_t)ragged_lanes(), work_bytes / slice) : 1;
-    if (lanes > n_sets) lanes = n_sets;
-    if (lanes < 1) lanes = 1;  // (a workspace below one slice is reported by smh_frontend_f32)
-    hipStream_t caller = (hipStream_t)stream;
-    LanePool *pool = nullptr;
-    if (lanes > 1) {
-        rc = lane_pool(&pool);
-        if (rc) return rc;
-        SMH_CHECK_HIP(hipEventRecord(pool->fork, caller));
-        for (int i = 0; i < lanes; ++i) SMH_CHECK_HIP(hipStreamWaitEvent(pool->st[i], pool->fork, 0));
-    }
-    int set = 0, err = SMH_OK;
-    for (int b = 0; b < B; ++set) {
-        const int e = run_end(h_offsets, h_lengths, B, b);
-        float *pt = patches && p.nP[b] > 0 ? d_patches + (size_t)p.patch_off[b] * prow : nullptr;
-        const int lane = lanes > 1 ? set % lanes : 0;
-        rc = smh_frontend_f32(ctx, d_audio + h_offsets[b], e - b, h_lengths[b], pt ? W : 0, pt ? shift : 0, d_fv + p.fv_off[b], pt,
-                              (char *)d_work + (lanes > 1 ? (size_t)lane * slice : 0), lanes > 1 ? slice : work_bytes, nullptr, nullptr,
-                              nullptr, lanes > 1 ? (void *)pool->st[lane] : stream);
-        if (rc < 0) {
-            err = rc;
-            break;
-        }
-        b = e;
-    }
-    if (lanes > 1)  // join also on an error: the caller's stream must not run ahead of what was enqueued
-        for (int i = 0; i < lanes; ++i) {
-            SMH_CHECK_HIP(hipEventRecord(pool->join[i], pool->st[i]));
-            SMH_CHECK_HIP(hipStreamWaitEvent(caller, pool->join[i], 0));
-        }
-    return err;
 }

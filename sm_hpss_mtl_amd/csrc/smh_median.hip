@@ -159,8 +159,8 @@ int launch_small(const float *S, int B, int K, int T, int w, int along_t, float 
     return smh::launch_status("median_small_kernel");
 }
 
-// harm_tmajor: 0 = (B,K,T), 1 = (B,T,K), 2 = (B, ceil(T/16), K, 16) (block-split kernels, single-tile clips only; any
-// other kernel writes layout 1 instead).  *written (optional) receives the layout that was produced.
+// harm_tmajor: 0 = (B,K,T), 1 = (B,T,K), 2 = (B, ceil(T/16), K, 16) (block-split kernels; any other kernel writes layout 1
+// instead).  *written (optional) receives the layout that was produced.
 int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, hipStream_t st,
            int harm_tmajor = 0, int *written = nullptr) {
     if (written) *written = harm_tmajor;
@@ -199,10 +199,7 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
             return smh::launch_status("hpss_median_persist_kernel");
         }
     }
-    if (harm_tmajor == 2 && p.ntiles != 1) {
-        harm_tmajor = 1;
-        if (written) *written = 1;
-    }
+    // (layout 2 is also written tile by tile: the blocked walker addresses harm[t / 16][k][t % 16] by absolute frame)
     if (const SplitEntry *se = no_split ? nullptr : find_split_kernel(lh, lp)) {
         Plan q = p;
         if (make_split_roles(K, p.TT, lh, lp, se->threads / 64, &q)) {
@@ -210,7 +207,7 @@ int launch(const float *S, int B, int K, int T, int lh, int lp, float *harm, flo
             dim3 grid(q.ntiles, B), block((q.nwh + q.nwp) * 64);
             const bool probe_noload = smh::probe_env("SMH_MEDIAN_PROBE_NOLOAD") != nullptr;  // timing experiment, outputs invalid
             hipLaunchKernelGGL(se->fn, grid, block, q.lds, st, S, harm, perc, K, T, q.TT, q.stride, q.nsh, q.nsp, q.nwh,
-                               harm_tmajor, probe_noload ? 1.f : -__builtin_inff(), __builtin_inff());
+                               harm_tmajor, probe_noload ? 1.f : -__builtin_inff(), __builtin_inff(), nullptr, nullptr, 0);
             return smh::launch_status("hpss_median_split_kernel");
         }
     }
@@ -240,6 +237,39 @@ bool fast_ok(int n, int w) { return w >= 3 && w / 2 + 4 < n; }
 }  // namespace
 
 namespace smh_median {
+// ---- clips of different lengths in one launch (smh_rag.h) ----
+// Frame tile of the ragged launch: the widest tile -- a multiple of 4 frames, so that the blocked harm rows start on float4
+// boundaries -- whose halo columns fit the LDS budget of two workgroups per CU (K = 201, l_harm = 21: 76 frames, 96 columns).
+int rag_tile_frames(int K, int lh, int lp, int *stride) {
+    static const bool no_split = getenv("SMH_MEDIAN_NOSPLIT") != nullptr;
+    if (no_split || !(lh && lp) || !find_split_kernel(lh, lp)) return 0;
+    const int hh = lh / 2;
+    const int budget_words = (smh::kLdsBytesPerCU / 2 - 1024) / 4;
+    int maxcols = budget_words / K;
+    if ((maxcols & 1) == 0) maxcols -= 1;
+    int TT = (maxcols - 2 * hh) & ~3;
+    if (TT < 2 * hh + 8) return 0;
+    if (stride) *stride = (TT + 2 * hh) | 1;
+    return TT;
+}
+
+int launch_rag(const float *d_S, float *d_harm, float *d_perc, int K, int lh, int lp, const smh_rag::Clip *d_clips,
+               const smh_rag::Item *d_items, int n_items, hipStream_t st) {
+    if (n_items <= 0) return SMH_OK;
+    int stride = 0;
+    const int TT = rag_tile_frames(K, lh, lp, &stride);
+    const SplitEntry *se = TT ? find_split_kernel(lh, lp) : nullptr;
+    Plan q;
+    if (!se || !make_split_roles(K, TT, lh, lp, se->threads / 64, &q))
+        return smh::set_error(SMH_E_INVALID, "ragged medians: no block-split kernel for (l_harm,l_perc)=(%d,%d), K=%d", lh, lp, K);
+    const size_t lds = (size_t)K * stride * sizeof(float);
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)se->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)(8 * (((long long)n_items + 7) / 8));
+    hipLaunchKernelGGL(se->fn, dim3(grid), dim3((q.nwh + q.nwp) * 64), lds, st, d_S, d_harm, d_perc, K, 0, TT, stride, q.nsh, q.nsp,
+                       q.nwh, 2, -__builtin_inff(), __builtin_inff(), d_clips, d_items, n_items);
+    return smh::launch_status("hpss_median_split_kernel (ragged)");
+}
+
 // Fused-pipeline entry: both filters in one launch, harm optionally time-major (B,T,K).
 // Returns 1 if the time-major layout was produced, 0 if the reference layout was used, <0 on error.
 int launch_hpss(const float *S, int B, int K, int T, int lh, int lp, float *harm, float *perc, int want_tmajor,

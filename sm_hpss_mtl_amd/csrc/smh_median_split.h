@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "smh_median_kernel.h"
+#include "smh_rag.h"
 
 namespace smh_median {
 
@@ -295,20 +296,37 @@ struct SplitCfg {
 };
 
 // Same arguments and tile as hpss_median_kernel; LH / LP = 0 disables that role.
+// rag != nullptr (smh_rag.h): clips of DIFFERENT lengths in one launch -- n_items (clip, frame tile) items, in clip-major order cut
+// into 8 contiguous ranges (one per XCD: neighbouring tiles share their halo columns in that L2), per-clip T and buffer offsets from
+// the descriptor table, harm in the 16-frame blocked layout.  Selection only: a clip's medians do not depend on how it was tiled.
 template <int LH, int LP>
 __global__ void __launch_bounds__((SplitCfg<LH, LP>::kThreads), (SplitCfg<LH, LP>::kWavesPerSimd))
 hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, float *__restrict__ perc, int K, int T,
-                         int TT, int stride, int nsh, int nsp, int nwh, int harm_tmajor, float probe, float) {
+                         int TT, int stride, int nsh, int nsp, int nwh, int harm_tmajor, float probe, float,
+                         const smh_rag::Clip *__restrict__ rag, const smh_rag::Item *__restrict__ items, int n_items) {
     // probe > 0 (tools/gpu/r2_fusion_bound.sh, SMH_MEDIAN_PROBE_NOLOAD): the tile is NOT staged -- what the medians cost when
     // their input is already in LDS, i.e. the upper bound of fusing this kernel behind the STFT; the outputs are garbage
     extern __shared__ __attribute__((aligned(16))) float tile[];
     constexpr int HH = LH / 2;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
+    int b = blockIdx.y, tile_i = blockIdx.x;
+    size_t spec_off, harm_off;
+    if (rag) {
+        const unsigned total = (unsigned)n_items, per_xcd = (total + 7u) >> 3;
+        const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
+        if (j >= per_xcd || n >= total) return;
+        const smh_rag::Item item = items[n];
+        b = item.clip, tile_i = item.tile;
+        T = rag[b].T;
+        spec_off = (size_t)rag[b].spec_off, harm_off = (size_t)rag[b].harm_off;
+    } else {
+        spec_off = (size_t)b * K * T;
+        harm_off = harm_tmajor == 2 ? (size_t)b * ((T + 15) >> 4) * K * 16 : spec_off;
+    }
+    const int t0 = tile_i * TT;
     const int t1 = min(T, t0 + TT);
     const int c0 = max(0, t0 - HH), c1 = min(T, t1 + HH);
     const int ncols = c1 - c0;
-    const float *Sb = S + (size_t)b * K * T;
+    const float *Sb = S + spec_off;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nwaves = blockDim.x >> 6;
 
@@ -392,11 +410,9 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
                 const int te = min(t1, ts + seglen);
                 if (ts < te) {
                     const float *row = tile + k * stride - c0;
-                    char *ob = reinterpret_cast<char *>(harm + (size_t)b * K * T);
+                    char *ob = reinterpret_cast<char *>(harm + harm_off);
                     if (harm_tmajor == 2)  // (B, ceil(T/16), K, 16): the clip's image is ceil(T/16)*K*16 floats
-                        split_median_walk_blocked<LH, 1>(row, ts, te - ts, seglen, T,
-                                                         reinterpret_cast<char *>(harm + (size_t)b * ((T + 15) >> 4) * K * 16),
-                                                         (unsigned)K * 64u, (unsigned)k * 64u);
+                        split_median_walk_blocked<LH, 1>(row, ts, te - ts, seglen, T, ob, (unsigned)K * 64u, (unsigned)k * 64u);
                     else if (harm_tmajor)
                         split_median_walk<LH, 1, kStridedPlain>(row, 1, ts, te - ts, seglen, T, ob,
                                                                 (unsigned)(ts * K + k) * 4u, (unsigned)K * 4u);
@@ -418,7 +434,7 @@ hpss_median_split_kernel(const float *__restrict__ S, float *__restrict__ harm, 
                 if (ks < ke) {
                     const float *col = tile + (t0 + tt - c0);
                     split_median_walk<LP, 0, kStridedStream>(col, stride, ks, ke - ks, seglen, K,
-                                                             reinterpret_cast<char *>(perc + (size_t)b * K * T),
+                                                             reinterpret_cast<char *>(perc + spec_off),
                                                              (unsigned)(ks * T + t0 + tt) * 4u, (unsigned)T * 4u);
                 }
             }
@@ -519,9 +535,11 @@ const PersistEntry *find_persist_kernel(int lh, int lp, int threads);  // smh_me
 
 constexpr int kSplitMaxWindow = 21;  // 120 history registers; larger windows keep the delete/insert kernel
 
+using SplitFn = void (*)(const float *, float *, float *, int, int, int, int, int, int, int, int, float, float,
+                         const smh_rag::Clip *, const smh_rag::Item *, int);
 struct SplitEntry {
     int lh, lp, threads;
-    KernelFn fn;
+    SplitFn fn;
 };
 const SplitEntry *find_split_kernel(int lh, int lp);  // smh_median_split.hip
 

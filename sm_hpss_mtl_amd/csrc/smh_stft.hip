@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "smh_common.h"
+#include "smh_rag.h"
 
 namespace {
 
@@ -162,7 +163,8 @@ __device__ __forceinline__ float mag(float re, float im) { return __builtin_amdg
 
 __global__ void __launch_bounds__(kThreads)
 stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__restrict__ window,
-                const float2 *__restrict__ twM, const float2 *__restrict__ tw2M, float *__restrict__ S) {
+                const float2 *__restrict__ twM, const float2 *__restrict__ tw2M, float *__restrict__ S,
+                const smh_rag::Clip *__restrict__ rag, const smh_rag::Item *__restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int M = a.M;
     const int MP = pad(M) + 2;  // padded frame stride (float2)
@@ -171,17 +173,29 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
     float2 *buf0 = tw2 + (M + 1);
     float2 *buf1 = buf0 + a.tt * MP;
     int b = blockIdx.y, tile = blockIdx.x;
-    if (a.xcd_tiles > 0) {  // the (clip, tile) items in 8 contiguous ranges, one per XCD: stft400_kernel has the reasoning
-        const unsigned total = (unsigned)a.B * (unsigned)a.xcd_tiles, per_xcd = (total + 7u) >> 3;
+    size_t clip_off, spec_off;
+    if (rag) {  // ragged call (smh_rag.h): a.B items of clips of different lengths, in 8 contiguous ranges like the grid below
+        const unsigned total = (unsigned)a.B, per_xcd = (total + 7u) >> 3;
         const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
         if (j >= per_xcd || n >= total) return;
-        b = (int)(n / (unsigned)a.xcd_tiles), tile = (int)(n - (unsigned)b * (unsigned)a.xcd_tiles);
+        const smh_rag::Item item = items[n];
+        b = item.clip, tile = item.tile;
+        a.T = rag[b].T;
+        clip_off = (size_t)rag[b].audio_off, spec_off = (size_t)rag[b].spec_off;
+    } else {
+        if (a.xcd_tiles > 0) {  // the (clip, tile) items in 8 contiguous ranges, one per XCD: stft400_kernel has the reasoning
+            const unsigned total = (unsigned)a.B * (unsigned)a.xcd_tiles, per_xcd = (total + 7u) >> 3;
+            const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
+            if (j >= per_xcd || n >= total) return;
+            b = (int)(n / (unsigned)a.xcd_tiles), tile = (int)(n - (unsigned)b * (unsigned)a.xcd_tiles);
+        }
+        clip_off = (size_t)b * a.n_samples, spec_off = (size_t)b * a.K * a.T;
     }
     const int t0 = tile * a.tt;
     const int nf = min(a.tt, a.T - t0);
     for (int i = threadIdx.x; i < M; i += blockDim.x) tw[i] = twM[i];
     for (int i = threadIdx.x; i <= M; i += blockDim.x) tw2[i] = tw2M[i];
-    const float *clip = audio + (size_t)b * a.n_samples;
+    const float *clip = audio + clip_off;
 
     float2 *src = buf0, *dst = buf1;
     int Ns = 1;
@@ -203,7 +217,7 @@ stft_mag_kernel(StftArgs a, const float *__restrict__ audio, const float *__rest
     }
     __syncthreads();
     // real-FFT untangle + magnitude; frames fastest -> contiguous stores along t
-    float *Sb = S + (size_t)b * a.K * a.T + t0;
+    float *Sb = S + spec_off + t0;
     const float inv_nf = nf == a.tt ? a.inv_tt : 1.0f / (float)nf;
     for (int it = threadIdx.x; it < nf * a.K; it += blockDim.x) {
         const int k = fdiv(it, inv_nf), f = it - k * nf;
@@ -358,7 +372,7 @@ template <int ROW>  // float2 pitch of a phase-1 table row: 25, or 40 = the 25 e
 __global__ void __launch_bounds__(512, 4)
 stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window, const float2 *__restrict__ twM,
                const float2 *__restrict__ tw2M, float *__restrict__ S, int n_samples, int hop, int T, int F, int probe, int B,
-               int ntiles) {
+               int ntiles, const smh_rag::Clip *__restrict__ rag, const smh_rag::Item *__restrict__ items) {
     // probe (SMH_STFT_PROBE_NOSTORE, tools/gpu/r2_fusion_bound.sh): magnitudes computed but not stored -- the cost of S's trip to HBM
     constexpr int M = 200, K = 201;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -375,17 +389,31 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     // neighbouring tiles share were fetched twice.  The (clip, tile) items in clip-major order are cut into 8 contiguous ranges, one
     // per XCD: the same rule serves a batch of a thousand clips (an XCD owns 128 whole clips) and a single long file (an XCD owns an
     // eighth of its tiles).  ntiles == 0: the plain (tile, clip) grid.
+    // rag != nullptr (smh_rag.h): B work items of clips of DIFFERENT lengths, item n = (clip, tile) from the list, clip shapes and
+    // offsets from the descriptor table; the items are in clip-major order and cut into the same 8 ranges.
     int b = blockIdx.y, tile = blockIdx.x;
-    if (ntiles > 0) {
-        const unsigned total = (unsigned)B * (unsigned)ntiles, per_xcd = (total + 7u) >> 3;  // (the launch keeps B * ntiles below 2^31)
+    size_t clip_off, spec_off;
+    if (rag) {
+        const unsigned total = (unsigned)B, per_xcd = (total + 7u) >> 3;
         const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
         if (j >= per_xcd || n >= total) return;
-        b = (int)(n / (unsigned)ntiles), tile = (int)(n - (unsigned)b * (unsigned)ntiles);
+        const smh_rag::Item item = items[n];
+        b = item.clip, tile = item.tile;
+        T = rag[b].T;
+        clip_off = (size_t)rag[b].audio_off, spec_off = (size_t)rag[b].spec_off;
+    } else {
+        if (ntiles > 0) {
+            const unsigned total = (unsigned)B * (unsigned)ntiles, per_xcd = (total + 7u) >> 3;  // (the launch keeps B * ntiles below 2^31)
+            const unsigned j = blockIdx.x >> 3, n = (blockIdx.x & 7u) * per_xcd + j;
+            if (j >= per_xcd || n >= total) return;
+            b = (int)(n / (unsigned)ntiles), tile = (int)(n - (unsigned)b * (unsigned)ntiles);
+        }
+        clip_off = (size_t)b * n_samples, spec_off = (size_t)b * K * T;
     }
     const int t0 = tile * F, tid = threadIdx.x;
     const int nf = min(F, T - t0);
     const int nthr = blockDim.x;
-    const float *clip = audio + (size_t)b * n_samples + (size_t)t0 * hop;
+    const float *clip = audio + clip_off + (size_t)t0 * hop;
     const int dq1 = nthr / 25, dr1 = nthr - dq1 * 25;
     // Phase 1's audio is requested FIRST, for all of this thread's items at once (up to kRounds1 rounds of (frame, n2) items,
     // 8 float2 each), then the twiddle / window tables travel to LDS: one trip to memory per workgroup where there were
@@ -479,7 +507,7 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
     // phase 3: untangle + magnitude, one pair (k, M - k) per item.  Item it = k * nf + f, frames fastest (contiguous stores);
     // (k, f) advance by (nthr / nf, nthr % nf) with a carry instead of a division per item, and every address is a 32-bit
     // offset from a uniform base: the item used to spend more instructions on 64-bit index arithmetic than on the butterfly.
-    float *Sb = S + (size_t)b * K * T + t0;
+    float *Sb = S + spec_off + t0;
     const int dq = nthr / nf, dr = nthr - dq * nf;
     int k = tid / nf, f = tid - k * nf;
     for (; k <= M / 2; ) {
@@ -508,6 +536,59 @@ stft400_kernel(const float *__restrict__ audio, const float *__restrict__ window
 
 }  // namespace
 
+namespace {
+// the specialised 8 x 25 kernel serves n_fft = 400 with an even hop (frames start on 8-byte boundaries when the clip does)
+bool stft400_ok(const smh_ctx *ctx) {
+    return ctx->cfg.n_fft == 400 && ctx->M == 200 && ctx->cfg.win_length <= 400 && (ctx->cfg.hop % 2) == 0 && !getenv("SMH_STFT_GENERIC");
+}
+void generic_args(const smh_ctx *ctx, StftArgs &a) {
+    a.n_fft = ctx->cfg.n_fft, a.hop = ctx->cfg.hop, a.M = ctx->M, a.K = ctx->K;
+    a.n_stages = ctx->n_stages;
+    for (int i = 0; i < smh::kMaxFftStages; ++i) {
+        a.radix[i] = i < ctx->n_stages ? ctx->radix[i] : 1;
+        a.inv_nb[i] = (float)a.radix[i] / (float)a.M;
+    }
+    for (int i = 0, ns = 1; i < smh::kMaxFftStages; ++i) {
+        a.inv_ns[i] = 1.0f / (float)ns;
+        a.tmul[i] = a.M / (ns * a.radix[i]) > 0 ? a.M / (ns * a.radix[i]) : 0;
+        ns *= a.radix[i];
+        if (ns > a.M) ns = a.M;
+    }
+}
+constexpr int kRagFramesGeneric = 16;
+}  // namespace
+
+namespace smh_stft {
+int rag_frames(const smh_ctx *ctx, bool aligned8) { return stft400_ok(ctx) && aligned8 ? kRagFrames : kRagFramesGeneric; }
+
+// One launch for clips of different lengths (smh_rag.h).  A frame's transform does not depend on the frames it shares a workgroup
+// with, so every clip gets the bits smh_stft_mag_f32 gives it alone.
+int launch_rag(const smh_ctx *ctx, const float *d_audio, float *d_S, const smh_rag::Clip *d_clips, const smh_rag::Item *d_items,
+               int n_items, bool aligned8, hipStream_t st) {
+    if (n_items <= 0) return SMH_OK;
+    const unsigned grid = (unsigned)(8 * (((long long)n_items + 7) / 8));
+    if (stft400_ok(ctx) && aligned8) {
+        const int F = kRagFrames;
+        const size_t lds = sizeof(float2) * (8 * 25 + 202 + 8 * 25 + (size_t)F * kMP400);
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft400_kernel<25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(stft400_kernel<25>, dim3(grid), dim3(256), lds, st, d_audio, ctx->d_window, ctx->d_twM, ctx->d_tw2M, d_S, 0,
+                           ctx->cfg.hop, 0, F, 0, n_items, 0, d_clips, d_items);
+        return smh::launch_status("stft400_kernel (ragged)");
+    }
+    StftArgs a;
+    generic_args(ctx, a);
+    a.n_samples = 0, a.T = 0, a.tt = kRagFramesGeneric, a.inv_tt = 1.0f / (float)a.tt;
+    const int MP = a.M + (a.M >> 4) + 2;
+    const size_t lds = sizeof(float2) * ((size_t)a.M + (a.M + 1) + 2 * (size_t)a.tt * MP);
+    SMH_REQUIRE(lds <= 150 * 1024, "ragged STFT: n_fft=%d too large for the LDS FFT", a.n_fft);
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)stft_mag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    a.B = n_items, a.xcd_tiles = 0;
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(grid), dim3(kThreads), lds, st, a, d_audio, ctx->d_window, ctx->d_twM, ctx->d_tw2M, d_S,
+                       d_clips, d_items);
+    return smh::launch_status("stft_mag_kernel (ragged)");
+}
+}  // namespace smh_stft
+
 extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samples, float *d_S,
                                 void *stream) {
     SMH_REQUIRE(ctx && (d_audio || B == 0) && (d_S || B == 0), "smh_stft_mag_f32: null argument");
@@ -516,8 +597,8 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
     SMH_REQUIRE(T >= 1, "smh_stft_mag_f32: clip of %d samples is shorter than n_fft=%d", n_samples, ctx->cfg.n_fft);
     if (B == 0) return SMH_OK;
     // n_fft = 400 with 8-byte aligned frames: the specialised 8 x 25 kernel (SMH_STFT_GENERIC=1 forces the generic one)
-    if (ctx->cfg.n_fft == 400 && ctx->M == 200 && ctx->cfg.win_length <= 400 && (ctx->cfg.hop % 2) == 0 &&
-        (n_samples % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0 && !getenv("SMH_STFT_GENERIC")) {
+    // (an odd clip length only matters for where the NEXT clip starts: a single clip keeps the specialised kernel)
+    if (stft400_ok(ctx) && ((n_samples % 2) == 0 || B == 1) && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0) {
         // frames per workgroup: <= 20 (37 KB of LDS, 128 VGPRs: FOUR 256-thread workgroups per CU), splitting T evenly (98 -> 5 x 20,
         // the last with 18).  25 frames (45 KB: three per CU) measured 69-71 us, 20 frames 64.6; 16 and fewer leave half of phase
         // 2's threads idle (8 items per frame) and are slower again.  tools/gpu/r2_stft_tune.sh sweeps it.
@@ -541,22 +622,12 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
         if (by_xcd) grid = dim3((unsigned)(8 * (((long long)B * nt + 7) / 8)), 1);
         const int probe = smh::probe_env("SMH_STFT_PROBE_NOSTORE") ? 1 : 0;  // timing experiment, S is not written
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, d_audio, ctx->d_window, ctx->d_twM,
-                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe, B, by_xcd ? nt : 0);
+                           ctx->d_tw2M, d_S, n_samples, ctx->cfg.hop, T, F, probe, B, by_xcd ? nt : 0, nullptr, nullptr);
         return smh::launch_status("stft400_kernel");
     }
     StftArgs a;
-    a.n_samples = n_samples, a.n_fft = ctx->cfg.n_fft, a.hop = ctx->cfg.hop, a.M = ctx->M, a.K = ctx->K, a.T = T;
-    a.n_stages = ctx->n_stages;
-    for (int i = 0; i < smh::kMaxFftStages; ++i) {
-        a.radix[i] = i < ctx->n_stages ? ctx->radix[i] : 1;
-        a.inv_nb[i] = (float)a.radix[i] / (float)a.M;
-    }
-    for (int i = 0, ns = 1; i < smh::kMaxFftStages; ++i) {
-        a.inv_ns[i] = 1.0f / (float)ns;
-        a.tmul[i] = a.M / (ns * a.radix[i]) > 0 ? a.M / (ns * a.radix[i]) : 0;
-        ns *= a.radix[i];
-        if (ns > a.M) ns = a.M;
-    }
+    generic_args(ctx, a);
+    a.n_samples = n_samples, a.T = T;
     // frames per workgroup: <= 16, chosen to split T evenly (T=98 -> 7 tiles of 14)
     const int max_tt = 16;
     const int ntiles = (T + max_tt - 1) / max_tt;
@@ -575,6 +646,6 @@ extern "C" int smh_stft_mag_f32(const smh_ctx *ctx, const float *d_audio, int B,
     dim3 grid(ntg, B), block(kThreads);
     if (xcd_grid) grid = dim3((unsigned)(8 * (((long long)B * ntg + 7) / 8)), 1);
     hipLaunchKernelGGL(stft_mag_kernel, grid, block, lds, (hipStream_t)stream, a, d_audio, ctx->d_window, ctx->d_twM,
-                       ctx->d_tw2M, d_S);
+                       ctx->d_tw2M, d_S, nullptr, nullptr);
     return smh::launch_status("stft_mag_kernel");
 }

@@ -372,9 +372,21 @@ class TrainingMixin:
         # Row-weighted sums: under data parallel every rank evaluates its own shard of every batch and the all-reduce below
         # turns the shard means into the mean over the global batch -- the number a single device would report, and the SAME
         # number on every rank (EarlyStopping / ModelCheckpoint decide on it).  Single process: a plain mean over the batches.
+        # The weights are rows / unit, unit = the largest first shard over the ranks (one MAX all-reduce per call): equal shards
+        # weigh exactly 1.0, so the sums -- and with one rank the result, to the last bit -- are the single process's
+        # ((v * rows) / rows is not v in floating point).
         dist = process_group()
+        unit = []
+
+        def weight(rows):
+            if dist is None:
+                return 1.0
+            if not unit:
+                unit.append(max(float(_host_collective([float(rows)], "max", dist)[0]), 1.0))
+            return float(rows) / unit[0]
+
         if self._device_evaluate_ok():
-            tot, cnt = self._evaluate_device(x, y, steps, dist is not None)
+            tot, cnt = self._evaluate_device(x, y, steps, weight)
             if dist is not None:
                 red = _host_collective(np.concatenate([tot, [cnt]]), "sum", dist)
                 tot, cnt = red[:-1], red[-1]
@@ -391,7 +403,7 @@ class TrainingMixin:
                 tot, cnt = None, 0.0
                 for _ in range(int(steps)):
                     bx, by = next(x)
-                    rows = float(len(bx)) if dist is not None else 1.0  # Keras averages the batch values (equal batch sizes)
+                    rows = weight(len(bx))  # Keras averages the batch values (equal batch sizes)
                     v = np.array(self._losses_inference(bx, by), np.float64) * rows
                     tot = v if tot is None else tot + v
                     cnt += rows
@@ -408,7 +420,7 @@ class TrainingMixin:
                 and hasattr(getattr(self, "lib", None), "smh_model_eval_losses_f32") and getattr(self, "block_variant", 0) == 0
                 and os.environ.get("SMH_EVAL_HOST", "0") != "1")
 
-    def _evaluate_device(self, x, y, steps, weighted):
+    def _evaluate_device(self, x, y, steps, weight):
         """evaluate() without a host round trip per batch: forward, then `smh_model_eval_losses_f32` adds the batch's mean losses and
         accuracy (float64, Keras' clipping: the arithmetic of `_losses_inference`) to device sums; ONE read-back at the end.
         Returns (unnormalised sums in metrics order, total weight) like the host loop.  SMH_EVAL_HOST=1 keeps the host loop."""
@@ -418,26 +430,26 @@ class TrainingMixin:
         lw = (C.c_double * (nh + 1))(*[float((self.loss_weights or {}).get(n, 1.0)) for n in self.output_names])
         l2 = float(self._l2_penalty())  # the weights do not change while evaluating
 
-        def one(bx, by, by_rows):
+        def one(bx, by, weight_of):
             if isinstance(bx, np.ndarray):
                 bx = torch.from_numpy(np.ascontiguousarray(bx, dtype=np.float32))
             out = self.forward_device(bx.to(device="cuda", dtype=torch.float32))
             tgt = by if (isinstance(by, torch.Tensor) and by.is_cuda and by.dim() == 2) else self.pack_targets(by)
             if tgt.shape[0] != out.shape[0]:
                 raise ValueError("%d inputs but %d target rows" % (out.shape[0], tgt.shape[0]))
-            w = float(out.shape[0]) if by_rows else 1.0  # Keras averages the batch values; data parallel: row-weighted (see evaluate)
+            w = float(weight_of(out.shape[0]))  # Keras averages the batch values; data parallel: row-weighted (see evaluate)
             _lib.check(self.lib.smh_model_eval_losses_f32(self._h, C.c_void_p(out.data_ptr()), C.c_void_p(tgt.data_ptr()), out.shape[0],
                                                           C.c_double(w), lw, C.c_double(l2), C.c_void_p(sums.data_ptr()), _cur_stream()),
                        "smh_model_eval_losses_f32")
             return w
 
         if y is not None:
-            cnt = one(x, y, True)  # arrays: one batch, weighted by its rows like the host path
+            cnt = one(x, y, float)  # arrays: one batch, weighted by its rows like the host path
         else:
             if steps is None:
                 raise ValueError("evaluate(generator) needs steps=")
             for _ in range(int(steps)):
-                cnt += one(*next(x), weighted)
+                cnt += one(*next(x), weight)
         self.check_status()  # one synchronisation for the whole pass; a device-side give-up raises here
         return sums.cpu().numpy(), cnt  # already in metrics order: [loss, <per-output losses>, 3C_accuracy]
 
