@@ -102,51 +102,70 @@ __device__ __forceinline__ bool xcd_item(int n_items, unsigned &n) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // rag_walk_kernel: the bin walk of features_half_kernel (smh_feat.hip) for clips beyond the LDS image.  One workgroup per
-// (clip, 128-frame chunk): 2 x nseg waves = (half, row segment), lane = PAIR of frames; a wave walks the bins of its segment once,
+// (clip, 128-frame chunk, half): nseg waves = row segments, lane = PAIR of frames; a wave walks the bins of its segment once,
 // evaluates this half's soft mask  S own^2 / (own^2 + other^2)  per bin (lib/preprocessing.py:418; librosa.util.softmask with
 // power 2) and adds it into the pending mel filters (:419-422); a finished filter's SUM goes to the featuregram row (the dB
 // conversion needs the array's maximum, which only exists after the launch) and into the running maximum of its (clip, half) array.
 // Even T: 8-byte loads and stores; odd T: two 4-byte accesses per pair, the lone last frame paired with itself.
 // ---------------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Addresses in the walk are a buffer descriptor of the clip's array (four SGPRs, built from wave-uniform values), a wave-uniform
+// byte offset of the row (soffset) and a 32-bit lane offset in bytes (voffset): buffer_load_dwordx2 v, v_off, s[rsrc], s_row offen.
+// Written as plain pointers hipcc keeps a 64-bit pointer per lane and array and adds every row offset to it with a
+// v_lshl_add_u64 (140 of them in the first version of this kernel, 13 spilled registers at 80 VGPRs).
+template <bool EVEN>
+__device__ __forceinline__ f32x2 load_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned d1) {
+    if constexpr (EVEN) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+    } else {
+        return f32x2{__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)),
+                     __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff + 4u * d1, soff, 0))};
+    }
+}
+
 template <int NP, bool EVEN>
-__device__ __forceinline__ void walk_pairs(const FeatPlan &fp, int seg, int half, int lane, int chunk, const float *__restrict__ S,
-                                           const float *__restrict__ harmc, const float *__restrict__ perc, int K, int T, int rows,
-                                           float *__restrict__ fvc, float &mx) {
+__device__ __forceinline__ void walk_pairs(const FeatPlan &fp, int seg, int half, int lane, int chunk, const float *S,
+                                           const float *harmc, const float *perc, int K, int T, int rows, float *fvc, float &mx) {
     const int t0 = chunk * kWalkFrames + 2 * lane;
     const bool active = t0 < T;
     const int tp = min(t0, EVEN ? T - 2 : T - 1);  // this lane's pair starts here (an even frame)
-    const int d1 = (EVEN || tp + 1 < T) ? 1 : 0;   // the second frame of the pair, or the first again
+    const unsigned d1 = (EVEN || tp + 1 < T) ? 1u : 0u;   // the second frame of the pair, or the first again
     const int m1 = fp.m1[seg], kbeg = fp.kbeg[seg], kend = fp.kend[seg];
     int mcur = fp.m0[seg];
     const float *plan = fp.plan + fp.off[seg];
     f32x2 acc[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) acc[e] = f32x2{0.f, 0.f};
-    float *fvrow = fvc + (size_t)half * rows * T + tp;
+    const unsigned spec_bytes = 4u * (unsigned)K * (unsigned)T, harm_bytes = 64u * (unsigned)K * (unsigned)((T + 15) >> 4);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(S), 0, spec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(perc), 0, spec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(harmc), 0, harm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(fvc, 0, 8u * (unsigned)rows * (unsigned)T, 0x00020000);
+    // lane offsets: lo = the pair in a (K, T) row, ho = in bin 0 of the blocked harm image (T / 16, K, 16)
+    const unsigned lo = 4u * (unsigned)tp, ho = 4u * (unsigned)((tp >> 4) * K * 16 + (tp & 15));
+    // "own" = the median this half's mask favours (harm for H, perc for P), chosen once: descriptor, bin stride and lane offset
+    const __amdgpu_buffer_rsrc_t r_own = half ? rP : rH, r_oth = half ? rH : rP;
+    const unsigned own_st = half ? 4u * (unsigned)T : 64u, oth_st = half ? 64u : 4u * (unsigned)T;
+    const unsigned own_lo = half ? lo : ho, oth_lo = half ? ho : lo;
+    const unsigned row_bytes = 4u * (unsigned)T, fv_half = (unsigned)half * (unsigned)rows * row_bytes;
     auto emit_first = [&]() {
         const f32x2 v = acc[0];
         mx = fmaxf(mx, fmaxf(v.x, v.y));
         if (active) {
-            float *o = fvrow + (size_t)mcur * T;
+            const unsigned soff = fv_half + (unsigned)mcur * row_bytes;  // wave-uniform row
             if constexpr (EVEN) {
-                *reinterpret_cast<f32x2 *>(o) = v;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, rF, lo, soff, 0);
             } else {
-                o[0] = v.x;
-                if (d1) o[1] = v.y;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rF, lo, soff, 0);
+                if (d1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rF, lo + 4u, soff, 0);
             }
         }
 #pragma unroll
         for (int e = 0; e + 1 < NP; ++e) acc[e] = acc[e + 1];
         acc[NP - 1] = f32x2{0.f, 0.f};
         ++mcur;
-    };
-    const float *Sb = S + tp, *Pb = perc + tp;
-    const float *Hb = harmc + (size_t)(tp >> 4) * K * 16 + (tp & 15);
-    const float *OwnB = half ? Pb : Hb, *OthB = half ? Hb : Pb;
-    const int own_st = half ? T : 16, oth_st = half ? 16 : T;
-    auto load2 = [&](const float *p) {
-        if constexpr (EVEN) return *reinterpret_cast<const f32x2 *>(p);
-        else return f32x2{p[0], p[d1]};
     };
     constexpr int kBatch = 8;  // bins of loads in flight per lane
     for (int k0 = kbeg; k0 < kend; k0 += kBatch) {
@@ -155,10 +174,10 @@ __device__ __forceinline__ void walk_pairs(const FeatPlan &fp, int seg, int half
         int ne[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const int kk = min(k0 + u, K - 1);
-            sv[u] = load2(Sb + (size_t)kk * T);
-            ov[u] = load2(OwnB + (size_t)kk * own_st);
-            tv[u] = load2(OthB + (size_t)kk * oth_st);
+            const unsigned kk = (unsigned)min(k0 + u, K - 1);
+            sv[u] = load_pair<EVEN>(rS, lo, kk * row_bytes, d1);
+            ov[u] = load_pair<EVEN>(r_own, own_lo, kk * own_st, d1);
+            tv[u] = load_pair<EVEN>(r_oth, oth_lo, kk * oth_st, d1);
             const int pi = min(k0 + u, kend - 1) - kbeg;  // wave-uniform: scalar loads
             wq[u] = *reinterpret_cast<const float4 *>(plan + (size_t)pi * 8);
             ne[u] = __float_as_int(plan[(size_t)pi * 8 + 4]);
@@ -199,18 +218,21 @@ __device__ __forceinline__ void walk_pairs(const FeatPlan &fp, int seg, int half
     while (mcur < m1) emit_first();
 }
 
+// (80 VGPRs: three 8-wave workgroups per CU, like features_half_kernel -- the walk lives on loads in flight)
 template <int NP>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512, 6)
 rag_walk_kernel(FeatPlan fp, const float *__restrict__ S, const float *__restrict__ harmb, const float *__restrict__ perc, int K, int rows,
                 float *__restrict__ fv, int *__restrict__ maxkeys, const Clip *__restrict__ clips, const Item *__restrict__ items,
                 int n_items) {
+    // item list entry n / 2, half n & 1: the two halves of a chunk read the same S / harm / perc and sit next to each other in
+    // their XCD's dispatch order (the second one's loads come from that L2)
     unsigned n;
-    if (!xcd_item(n_items, n)) return;
-    const Item item = items[n];
+    if (!xcd_item(2 * n_items, n)) return;
+    const Item item = items[n >> 1];
+    const int half = n & 1;
     const Clip &c = clips[item.clip];
     const int T = c.T;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int half = wave >= fp.nseg ? 1 : 0, seg = wave - half * fp.nseg;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float mx = 0.f;  // sums of non-negative terms
     if (T & 1)
         walk_pairs<NP, false>(fp, seg, half, lane, item.tile, S + c.spec_off, harmb + c.harm_off, perc + c.spec_off, K, T, rows,
@@ -236,8 +258,7 @@ __device__ __forceinline__ float final_value(float x, float lim, int log_db) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // rag_stats_kernel: StandardScaler statistics of one featuregram row per wave (lib/preprocessing.py:211-214, 221-224: per row over
 // the frames, population variance, constant rows left unscaled -- sklearn's _is_constant_feature / _handle_zeros_in_scale), in
-// float64, on the final dB values, which are formed on the fly from the walk's sums (the row is read twice: mean, then centred
-// squares).  Rows of all long clips of the call are numbered consecutively: clip list[i] owns rows i * R2 .. (i + 1) * R2 - 1.
+// float64, on the final dB values, which are formed on the fly from the walk's sums.  Rows of all long clips of the call are numbered consecutively: clip list[i] owns rows i * R2 .. (i + 1) * R2 - 1.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 rag_stats_kernel(const float *__restrict__ fv, const int *__restrict__ maxkeys, int log_db, int rows, const Clip *__restrict__ clips,
@@ -252,17 +273,19 @@ rag_stats_kernel(const float *__restrict__ fv, const int *__restrict__ maxkeys, 
     const int T = c.T;
     const float *x = fv + c.fv_off + (size_t)r * T;
     const float lim = floor_of_max(maxkeys[2 * b + (r >= rows ? 1 : 0)]);
-    double s = 0.0;
-    for (int t = lane; t < T; t += 64) s += (double)final_value(x[t], lim, log_db);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const double mean = s / (double)T;
-    double q = 0.0;
+    // one pass: sums of d = value - (the row's first value) and of d^2 in float64 (|d| <= 80 dB over at most 2^31 frames: the
+    // shifted second moment loses nothing that a float32 patch could show)
+    const double x0 = (double)final_value(x[0], lim, log_db);
+    double s = 0.0, q = 0.0;
     for (int t = lane; t < T; t += 64) {
-        const double d = (double)final_value(x[t], lim, log_db) - mean;
+        const double d = (double)final_value(x[t], lim, log_db) - x0;
+        s += d;
         q += d * d;
     }
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-    const double var = q / (double)T;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off), q += __shfl_xor(q, off);
+    const double md = s / (double)T;
+    const double mean = x0 + md;
+    const double var = fmax(q / (double)T - md * md, 0.0);
     const double eps = 2.220446049250313e-16;
     const double nm = (double)T * mean * eps;
     const bool constant = var <= (double)T * eps * var + nm * nm;
@@ -297,7 +320,7 @@ rag_final_kernel(float *__restrict__ fv, const int *__restrict__ maxkeys, int lo
     const bool want = patches != nullptr && c.nP > 0;
     const float limH = floor_of_max(maxkeys[2 * item.clip]), limP = floor_of_max(maxkeys[2 * item.clip + 1]);
     float *g = fv + c.fv_off + t0;
-    constexpr int kB = 4;  // rows of loads in flight per wave
+    constexpr int kB = 6;  // rows of loads in flight per wave
     for (int r0 = wave; r0 < R2; r0 += nw * kB) {
         float v[kB];
 #pragma unroll
@@ -361,13 +384,15 @@ constexpr size_t kFixedBytes = 8 * 256;  // alignment slack between the regions 
 
 bool rag_context_ok(const smh_ctx *ctx) {
     if (!ctx->feat_walk_ok || getenv("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS") || getenv("SMH_RAGGED_PERFILE")) return false;
-    if (ctx->feat_nseg[1] < 1 || 2 * ctx->feat_nseg[1] > 16) return false;
+    if (ctx->feat_nseg[1] < 1 || ctx->feat_nseg[1] > 8) return false;
     const size_t final_lds = sizeof(float) * (size_t)2 * ctx->feat_rows * (kFinalFrames + 1);
     if (final_lds > 150 * 1024) return false;
     return smh_median::rag_tile_frames(ctx->K, ctx->cfg.l_harm, ctx->cfg.l_perc, nullptr) > 0;
 }
 // the block-split walkers fold once per side: window / 2 + 4 < axis length (smh_median.hip: fast_ok)
 bool rag_clip_ok(const smh_ctx *ctx, int T) {
+    // (the streaming kernels address a clip's rows with 32-bit offsets: K * T and 2 * rows * T below 2^29 elements -- a day of audio)
+    if ((long long)(ctx->K + 16) * T >= (1ll << 29) || (long long)2 * ctx->feat_rows * T >= (1ll << 29)) return false;
     return ctx->cfg.l_harm / 2 + 4 < T && ctx->cfg.l_perc / 2 + 4 < ctx->K && T >= 2;
 }
 
@@ -444,6 +469,8 @@ int run_sub_batch(const smh_ctx *ctx, const RagGeom &g, const float *d_audio, co
     if (rc) return rc;
     rc = smh_median::launch_rag(d_S, d_harm, d_perc, g.K, ctx->cfg.l_harm, ctx->cfg.l_perc, d_clips, items_at(o_med), (int)it_med.size(), st);
     if (rc) return rc;
+    // (The LDS-image clips' small grids were tried on a side stream beside the streaming kernels: the fork / join events cost the host
+    // 0.4 ms per call and the call got slower, 0.74 -> 1.10 ms per 256 files; everything stays on the caller's stream.)
     rc = smh_feat::launch_features_rag(ctx, d_S, d_harm, d_perc, d_clips, list_at(o_l0), (int)list[0].size(), max_T[0], 1, W > 0 ? W : 1,
                                        shift > 0 ? shift : 1, d_fv, d_patches, st);
     if (rc) return rc;
@@ -452,12 +479,12 @@ int run_sub_batch(const smh_ctx *ctx, const RagGeom &g, const float *d_audio, co
     if (rc) return rc;
     if (!list[2].empty()) {
         const FeatPlan fp = smh_feat::feat_plan(ctx, 1);
-        const unsigned gw = (unsigned)(8 * (((long long)it_walk.size() + 7) / 8));
+        const unsigned gw = (unsigned)(8 * ((2 * (long long)it_walk.size() + 7) / 8));
         if (fp.pend <= 2)
-            hipLaunchKernelGGL(rag_walk_kernel<2>, dim3(gw), dim3(128 * fp.nseg), 0, st, fp, d_S, d_harm, d_perc, g.K, g.rows, d_fv, d_keys,
+            hipLaunchKernelGGL(rag_walk_kernel<2>, dim3(gw), dim3(64 * fp.nseg), 0, st, fp, d_S, d_harm, d_perc, g.K, g.rows, d_fv, d_keys,
                                d_clips, items_at(o_walk), (int)it_walk.size());
         else
-            hipLaunchKernelGGL(rag_walk_kernel<4>, dim3(gw), dim3(128 * fp.nseg), 0, st, fp, d_S, d_harm, d_perc, g.K, g.rows, d_fv, d_keys,
+            hipLaunchKernelGGL(rag_walk_kernel<4>, dim3(gw), dim3(64 * fp.nseg), 0, st, fp, d_S, d_harm, d_perc, g.K, g.rows, d_fv, d_keys,
                                d_clips, items_at(o_walk), (int)it_walk.size());
         rc = smh::launch_status("rag_walk_kernel");
         if (rc) return rc;

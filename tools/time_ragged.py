@@ -12,6 +12,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 MAXS = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 rng = np.random.default_rng(0)
 lens = [int(rng.uniform(1.0, MAXS) * 16000) // 2 * 2 for _ in range(B)]
+if os.environ.get("RAG_T_PARITY"):  # tuning: every file an even (0) or odd (1) number of frames
+    par = int(os.environ["RAG_T_PARITY"])
+    lens = [n if (1 + (n - 400) // 160) % 2 == par else n + 160 for n in lens]
 fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
 offs, o = [], 0
 for n in lens:
