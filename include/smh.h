@@ -247,10 +247,13 @@ int smh_model_out_dim(const smh_model *m);
  * (Proposed_Work_Results.py:520,586).  d_trunk (N, W, nb_filters) optional TCN output tap.      */
 int smh_model_forward_f32(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, void *stream);
 /* Error contract of the stream-ordered forwards (SURVEY 8(b) "Errors": the reference raises; a launch cannot).  Every
- * smh_model_forward_* only enqueues work, so a condition a kernel meets on the device -- today one: a wave of the barrier-free
- * block schedule whose dependency did not arrive within its bounded spin -- is recorded in the model's device error word and the
- * affected outputs are zero-filled.  smh_model_status waits for `stream`, returns SMH_OK or SMH_E_DEVICE (+ smh_last_error)
- * and clears the word.  The Python `predict` calls it before it hands results to the caller. */
+ * smh_model_forward_* (and the training forward inside smh_train_step_f32) only enqueues work, so a condition a kernel meets on the
+ * device -- today one: a wave whose dependency (a tile flag of the barrier-free block schedule, the partner half of a split tile of
+ * the barrier schedule) did not arrive within its bounded spin -- is recorded in the model's device error word; the affected
+ * outputs are NOT results (zero-filled by the barrier-free schedule, computed from a stale exchange by the split tile).
+ * smh_model_status waits for `stream`, returns SMH_OK or SMH_E_DEVICE (+ smh_last_error) and clears the word.  The Python side calls
+ * it wherever results leave the device or decide something: `predict`, the device `evaluate`, `patch_probabilities`, `train_on_batch`
+ * (sync=True) and once per epoch in `fit`. */
 int smh_model_status(smh_model *m, void *stream);
 
 /* download the (device-resident, possibly trained) weights in canonical order */

@@ -37,12 +37,15 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+LAB = False  # --lab: -DSMH_LAB, the measured-and-rejected implementation variants compiled in (smh_common.h: lab_env)
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src[:-4] + ".o")
     srcp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _headers_mtime()):
         return obj
-    cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *(["-DSMH_LAB"] if LAB else []), *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -65,4 +68,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    LAB = "--lab" in sys.argv
+    build(force="--force" in sys.argv or LAB)

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -36,6 +37,14 @@ inline int launch_status(const char *what) {
 // read only when SMH_ENABLE_PROBES=1 is set, and every affected launch says so on stderr.  Without that switch the variable is
 // ignored (one notice per variable).  Selectors that keep results valid (kernel A/B choices such as SMH_TCN_SKEW) use getenv.
 const char *probe_env(const char *name);
+// Implementation variants that the measurements rejected (the 16-wave network schedule, the LDS copy of the layer-0 weights, the
+// per-tap feature kernel as a forced choice) are only selectable in a lab build (python -m sm_hpss_mtl_amd.build --lab -> -DSMH_LAB):
+// the production library ignores their switches and does not contain the instantiations they select.
+#ifdef SMH_LAB
+inline const char *lab_env(const char *name) { return getenv(name); }
+#else
+inline const char *lab_env(const char *) { return nullptr; }
+#endif
 
 constexpr int kMaxFftStages = 12;
 constexpr int kLdsBytesPerCU = 160 * 1024;

@@ -39,6 +39,13 @@ const char *probe_env(const char *name) {
 
 extern "C" const char *smh_last_error(void) { return smh::g_err; }
 extern "C" int smh_version(void) { return 100; }
+extern "C" int smh_internal_lab(void) {  // 1: built with -DSMH_LAB (the rejected variants are compiled in and selectable)
+#ifdef SMH_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int smh_device_count(void) {
     int n = 0;

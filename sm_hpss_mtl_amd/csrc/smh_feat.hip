@@ -1226,7 +1226,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
     // bin-walk kernel: one workgroup per clip (SMH_FEAT_TAPS=1 forces the per-tap kernel below)
     const size_t lds_walk = sizeof(float) * (harm_tmajor ? (size_t)T * (K | 1) : 0) + 128;
     const int walk_waves = c->feat_nseg[0] * ((T + 63) / 64);
-    if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !getenv("SMH_FEAT_TAPS")) {
+    if (c->feat_walk_ok && lds_walk <= 150 * 1024 && walk_waves >= 1 && !smh::lab_env("SMH_FEAT_TAPS")) {
         const FeatPlan fp = feat_plan(c, 0);
         const int nwaves = std::min(16, walk_waves);
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)hp_feat_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk));
@@ -1249,7 +1249,7 @@ int launch_hp_feat(const smh_ctx *c, const float *S, const float *harm, const fl
 int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, const float *perc, int B, int T, int W,
                          int shift, int nP, float *fv, float *patches, const float *w0, float *x0p, hipStream_t st) {
     const int K = c->K, rows = c->feat_rows;
-    if (!c->feat_walk_ok || getenv("SMH_FEAT_TAPS")) return 0;
+    if (!c->feat_walk_ok || smh::lab_env("SMH_FEAT_TAPS")) return 0;
     if (x0p && (rows % 4 != 0 || rows > 128)) return 0;
     size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
     if (x0p) lds += sizeof(float) * 2 * rows * 32;  // the layer's weights
@@ -1270,7 +1270,7 @@ int launch_features_clip(const smh_ctx *c, const float *S, const float *harmb, c
         size_t ldh = sizeof(float) * ((size_t)rows * (T | 1) + 3 * (size_t)rows) + 64;
         // the layer-0 weights come straight from L2 (15 KB per half, shared by every workgroup): without an LDS copy a workgroup
         // needs 49 KB and THREE share a CU (77 VGPRs: 6 waves per SIMD) -- 127-130 -> 113-115 us; SMH_FEAT_W0LDS=1: the copy
-        const bool w0_l2 = getenv("SMH_FEAT_W0LDS") == nullptr;
+        const bool w0_l2 = smh::lab_env("SMH_FEAT_W0LDS") == nullptr;
         if (x0p && !w0_l2) ldh += sizeof(float) * rows * 32;
         const int probe = (stop & ~16) | (w0_l2 ? 16 : 0);
         // (the two halves of a clip back to back in their XCD's dispatch order: consecutive workgroups land on the same CU and the

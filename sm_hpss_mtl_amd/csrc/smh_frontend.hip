@@ -53,7 +53,7 @@ extern "C" int smh_features_ex_f32(const smh_ctx *ctx, const float *d_S, const f
 extern "C" int smh_features_blocked_ok(const smh_ctx *ctx, int T, int with_l0) {
     if (!ctx || T < 1) return 0;
     const int rows = ctx->feat_rows;
-    if (!ctx->feat_walk_ok || getenv("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS")) return 0;
+    if (!ctx->feat_walk_ok || smh::lab_env("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS")) return 0;
     if (with_l0 && (rows % 4 != 0 || rows > 128)) return 0;
     size_t lds = sizeof(float) * ((size_t)2 * rows * (T | 1) + 3 * (size_t)2 * rows) + 128;
     if (with_l0) lds += sizeof(float) * 2 * rows * 32;  // as launch_features_clip

@@ -78,9 +78,11 @@ struct smh_model {
     // bf16 operand cache of smh_model_forward_bf16 (smh_tcn_bf16.hip): rebuilt when `version` moves
     void *d_bf16 = nullptr;
     unsigned long long version = 1, bf16_version = 0;
-    // Device error word (smh_model_status).  A kernel that cannot produce results -- today: a wave of the skewed schedule whose
-    // dependency never arrived within its bounded spin -- ORs a bit in and zero-fills its workgroup's outputs; the host reads
-    // and clears it in smh_model_status.  Never a NaN payload: smh_tcn.hip is compiled -fno-honor-nans.
+    // Device error word (smh_model_status).  A kernel that cannot produce results -- today: a wave of the skewed schedule, or one
+    // half of a split last-round tile of the barrier schedule, whose partner never arrived within its bounded spin -- ORs a bit in;
+    // the skewed schedule also zero-fills its workgroup's outputs, the split tile leaves whatever it computed from the stale
+    // exchange (NOT results either way).  The host reads and clears the word in smh_model_status.  Never a NaN payload:
+    // smh_tcn.hip is compiled -fno-honor-nans.
     int *d_status = nullptr;
 };
 

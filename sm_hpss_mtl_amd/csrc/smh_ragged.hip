@@ -383,7 +383,7 @@ size_t clip_bytes(const RagGeom &g, const HostClip &c) {
 constexpr size_t kFixedBytes = 8 * 256;  // alignment slack between the regions of a sub-batch
 
 bool rag_context_ok(const smh_ctx *ctx) {
-    if (!ctx->feat_walk_ok || getenv("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS") || getenv("SMH_RAGGED_PERFILE")) return false;
+    if (!ctx->feat_walk_ok || smh::lab_env("SMH_FEAT_TAPS") || getenv("SMH_FEAT_TWO_KERNELS") || getenv("SMH_RAGGED_PERFILE")) return false;
     if (ctx->feat_nseg[1] < 1 || ctx->feat_nseg[1] > 8) return false;
     const size_t final_lds = sizeof(float) * (size_t)2 * ctx->feat_rows * (kFinalFrames + 1);
     if (final_lds > 150 * 1024) return false;

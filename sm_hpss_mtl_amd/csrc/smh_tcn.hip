@@ -1216,13 +1216,13 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
     if (skew && !getenv("SMH_TCN_WAVES")) nwaves = 8;
     if (skew) nwaves = std::min(nwaves, 8);
     // The 16-wave form of the skew schedule (weights in an LDS ring, four waves per SIMD): inference, when its ring fits beside
-    // the activations.  OPT-IN (SMH_TCN_SKEW16=1): measured on the bench shape it runs 135.7-136.2 us against 133.6-134.2 us for the
+    // the activations.  LAB BUILDS ONLY (-DSMH_LAB, then SMH_TCN_SKEW16=1; the production library does not instantiate it): measured on the bench shape it runs 135.7-136.2 us against 133.6-134.2 us for the
     // 8-wave form (tools/gpu/r3_net.sh) -- twice the waves per SIMD buy nothing, i.e. the loop is not short of waves to hide
     // latency behind: exact-f32 MFMA and the VALU work of the epilogues do not overlap.  Kept as the measured
     // experiment and as a third implementation the schedule-agreement test holds bit-identical to the other two.
     const size_t lds16 = sizeof(float) * (2 * (size_t)(a.GRP + 1) * SX + (size_t)kWeightRing * kBlockFloats + 128);  // + flags and scratch words
     bool skew16 = false;
-    if (const char *ev = getenv("SMH_TCN_SKEW16")) skew16 = atoi(ev) != 0 && skew && !tio && !a.trace && lds16 <= 156 * 1024;
+    if (const char *ev = smh::lab_env("SMH_TCN_SKEW16")) skew16 = atoi(ev) != 0 && skew && !tio && !a.trace && lds16 <= 156 * 1024;
     if (skew16) nwaves = 16, lds = lds16;
     // barrier schedule with two register sets and ONE tile in its last round (5, 9, ... tiles on 8 waves): that tile as two halves on
     // two waves of different SIMDs (half_tile_compute).  SMH_TCN_SPLIT=0 switches it off (tests: the two forms agree bit for bit).
@@ -1246,8 +1246,10 @@ int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, fl
         if (skew) SMH_LAUNCH_FWD(false, kSkew, true);
         else if (prefetch) SMH_LAUNCH_FWD(false, kPrefetch, true);
         else SMH_LAUNCH_FWD(false, kOneSet, true);
+#ifdef SMH_LAB
     } else if (skew16) {
         SMH_LAUNCH_FWD(false, kSkew16, false);
+#endif
     } else if (skew) {
         SMH_LAUNCH_FWD(false, kSkew, false);
     } else {
@@ -1347,8 +1349,8 @@ extern "C" int smh_model_status(smh_model *m, void *stream) {
     SMH_CHECK_HIP(hipStreamSynchronize(st));
     if (word == 0) return SMH_OK;
     SMH_CHECK_HIP(hipMemsetAsync(m->d_status, 0, sizeof(int), st));
-    return smh::set_error(SMH_E_DEVICE, "B3_MTL forward: device error word 0x%x (bit 0: a wave of the skewed block schedule gave up "
-                          "waiting for a dependency; the affected outputs were zero-filled and are not results)", word);
+    return smh::set_error(SMH_E_DEVICE, "B3_MTL forward: device error word 0x%x (bit 0: a wave gave up waiting for a tile flag of the "
+                          "skewed block schedule or for the partner half of a split tile; the affected outputs are not results)", word);
 }
 
 extern "C" size_t smh_model_num_params(const smh_model *m) { return m ? m->n_params : 0; }
@@ -1421,6 +1423,9 @@ extern "C" int smh_model_forward_dense_f32(const smh_model *m, const float *d_fv
                                            float *d_out, void *stream) {
     SMH_REQUIRE(m && d_fv && d_work && d_out, "smh_model_forward_dense_f32: null argument");
     SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_dense_f32: exists for block_variant 0 only");
+    SMH_REQUIRE((reinterpret_cast<uintptr_t>(d_work) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_fv) % 16) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d_out) % 4) == 0,
+                "smh_model_forward_dense_f32: d_fv and d_work are read / written with 16-byte accesses and must start on 16-byte boundaries");
     const int W = m->cfg.patch_size, F = m->cfg.n_feat;
     SMH_REQUIRE(F % 8 == 0, "smh_model_forward_dense_f32: n_feat=%d must be a multiple of 8 (two halves of whole k steps)", F);
     SMH_REQUIRE(shift >= 1 && Tc >= W, "smh_model_forward_dense_f32: needs shift >= 1 and at least patch_size=%d frames (Tc=%d, shift=%d); "

@@ -46,30 +46,68 @@ def to_categorical(labels, num_classes):
 
 
 class _ClassBuffer:
-    """One class's buffer of patches: grows file by file until it holds a batch, hands out the first batchSize rows."""
+    """One class's queue of patches, file by file, in the order the reference's loop would append them.  A file enters with the
+    NUMBER of patches it will yield (an integer contract of its length) and, once somebody needs them, its patches.  `take(n, lo, hi)`
+    pops the first n rows of the queue -- the class's share of the global batch -- and returns rows lo .. hi-1 of them: the whole
+    share in a single process, this rank's contiguous range under data parallel, so that a rank computes only the files its rows
+    come from (`pending(lo, hi)` names them)."""
 
     def __init__(self):
-        self.chunks, self.balance, self.meta = [], 0, []
+        self.files = []  # [spec, meta, n_rows_left, first_row_left, patches or None]
 
-    def add(self, patches, meta=None):
-        n = int(patches.shape[0])
-        if n == 0:
-            return
-        self.chunks.append(patches)
-        self.meta.extend([meta] * n)
-        self.balance += n
+    @property
+    def balance(self):
+        return sum(f[2] for f in self.files)
 
-    def take(self, n):
-        import torch
-        if isinstance(self.chunks[0], np.ndarray):
-            data = np.concatenate(self.chunks, axis=0)
+    def add(self, spec, meta, n, patches=None):
+        if patches is not None:
+            n = int(patches.shape[0])
+        if n > 0:
+            self.files.append([spec, meta, int(n), 0, patches])
+
+    def _overlapping(self, lo, hi):
+        pos = 0
+        for f in self.files:
+            a, b = pos, pos + f[2]
+            if a < hi and b > lo:
+                yield f, max(lo - a, 0), min(hi, b) - a  # the file's rows [u, v) of what is left of it
+            pos = b
+            if pos >= hi:
+                break
+
+    def pending(self, lo, hi):
+        """Files among the queue's rows lo .. hi-1 whose patches have not been computed yet."""
+        return [f for f, _, _ in self._overlapping(lo, hi) if f[4] is None]
+
+    def set_patches(self, f, patches, strict):
+        got = int(patches.shape[0])
+        want = f[2] + f[3]
+        if got != want:
+            if strict:
+                raise RuntimeError("file %r yields %d patches where its length promised %d: under data parallel the ranks decide a "
+                                   "batch's files from the promised counts and would drift apart" % (f[0], got, want))
+            f[2] = max(got - f[3], 0)
+        f[4] = patches
+
+    def take(self, n, lo=0, hi=None):
+        hi = n if hi is None else hi
+        parts = [f[4][f[3] + u:f[3] + v] for f, u, v in self._overlapping(lo, hi)]
+        meta, left = [], n
+        while left > 0:  # pop the first n rows of the queue
+            f = self.files[0]
+            k = min(left, f[2])
+            meta.extend([f[1]] * k)
+            f[2] -= k
+            f[3] += k
+            left -= k
+            if f[2] == 0:
+                self.files.pop(0)
+        if isinstance(parts[0], np.ndarray):
+            data = np.concatenate(parts, axis=0)
         else:
-            data = torch.cat(self.chunks, dim=0)
-        head, rest = data[:n], data[n:]
-        meta, self.meta = self.meta[:n], self.meta[n:]
-        self.chunks = [rest] if rest.shape[0] else []
-        self.balance -= n
-        return head, meta
+            import torch
+            data = torch.cat(parts, dim=0)
+        return data, meta
 
 
 # ---- device-resident featuregram cache ------------------------------------------------------------------------------------
@@ -79,7 +117,9 @@ class _ClassBuffer:
 # a byte budget); later batches start from the device copy: no np.load, no host-to-device copy -- and no host synchronisation, which
 # a pageable upload is, so the host can run ahead of the device and fit()'s side stream has something to overlap.  The key carries the
 # file's size and modification time: a rewritten cache file is read again.  SMH_FV_CACHE_GB sets the budget (0 disables; default a
-# quarter of the device's memory).
+# quarter of the device's memory), and an entry is only admitted while at least as much memory again stays FREE on the device
+# (torch.cuda.mem_get_info at insert time: several ranks or another tenant on the same GPU shrink the cache instead of running
+# out of memory).
 _FV_CACHE = OrderedDict()
 _FV_CACHE_BYTES = [0]
 
@@ -113,14 +153,21 @@ def _cached_featuregram(path, fresh=None):
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.load(path, allow_pickle=False), dtype=np.float32)).cuda()
     budget, nbytes = _fv_cache_budget(), t.numel() * 4
+    if os.environ.get("SMH_FV_CACHE_GB") is None:
+        try:  # default budget: never more than what keeps half of the currently free memory free
+            free, _ = torch.cuda.mem_get_info()
+            budget = min(budget, _FV_CACHE_BYTES[0] + free // 2)
+        except RuntimeError:
+            pass
     if nbytes <= budget:
-        evicted = False
+        cur = torch.cuda.current_stream()
         while _FV_CACHE and _FV_CACHE_BYTES[0] + nbytes > budget:
             _, old = _FV_CACHE.popitem(last=False)
             _FV_CACHE_BYTES[0] -= old.numel() * 4
-            evicted = True
-        if evicted:
-            torch.cuda.synchronize()  # a launch on another stream may still read what was just released
+            # the evicted tensor may still be read by work enqueued on this stream (fit's side stream builds batches from the
+            # cache): the allocator must not hand its memory out before that work is done -- record_stream instead of a
+            # device-wide synchronize in the middle of building a batch
+            old.record_stream(cur)
         _FV_CACHE[key] = t
         _FV_CACHE_BYTES[0] += nbytes
     return t
@@ -160,7 +207,9 @@ def _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, shift):
             out[i] = res["patches"][k]
             if PARAMS.get('save_features', True):  # get_featuregram(save_feat=True): the reference's .npy cache
                 os.makedirs(os.path.dirname(clips[i][2]), exist_ok=True)
-                np.save(clips[i][2], res["fv"][k].cpu().numpy())
+                tmp = "%s.%d.tmp.npy" % (clips[i][2], os.getpid())  # (two ranks may compute the same file: whole files only)
+                np.save(tmp, res["fv"][k].cpu().numpy())
+                os.replace(tmp, clips[i][2])
                 _cached_featuregram(clips[i][2], fresh=res["fv"][k])  # ... and stays on the device for the epochs to come
     for i, c in enumerate(clips):
         if c[0] == "fv":  # cached featuregram (device copy after its first use): standardise + patches only
@@ -185,6 +234,29 @@ def _n_patches_of_file(PARAMS, path, n_fft, W, shift, lengths_cache):
     if T < 1:
         return 0
     return lib.smh_num_patches(lib.smh_tiled_frames(T, int(W)), int(W), int(shift))
+
+
+def _n_patches_of_spec(PARAMS, spec, n_fft, n_mels, W, shift, lengths_cache):
+    """Patches the file(s) of `spec` will yield, before anything is computed: from the cached featuregram's header when the
+    reference's .npy cache holds it (its frame count is what `patches_from_featuregram` will see), else from the audio's length
+    (a mixture has the length of its speech file: the music is looped / cut to it, preprocessing.py:303-310)."""
+    from . import _lib
+    from .lib import preprocessing as pp
+    classname, sp, mu, db = spec
+    cache = pp.feature_cache_path(PARAMS['feature_opDir'], classname, sp, mu, db)
+    key = ("fv", cache)
+    if key in lengths_cache:
+        return lengths_cache[key]
+    if os.path.exists(cache):
+        try:
+            T = int(np.load(cache, mmap_mode="r", allow_pickle=False).shape[1])
+            lib = _lib.load()
+            n = lib.smh_num_patches(lib.smh_tiled_frames(T, int(W)), int(W), int(shift)) if T >= 1 else 0
+            lengths_cache[key] = n
+            return n
+        except (OSError, ValueError, IndexError):
+            pass
+    return _n_patches_of_file(PARAMS, mu if classname == 'music' else sp, n_fft, W, shift, lengths_cache)
 
 
 def _rank_world(rank, world):
@@ -226,10 +298,15 @@ def _check_same_state(dist, batch_count):
                            "seed numpy identically (the ranks build the same global batch and take their rows of it)" % batch_count)
 
 
-def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches_fn=None, rank=None, world=None, check_every=50):
+def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches_fn=None, rank=None, world=None, check_every=50,
+              count_fn=None, batch_patches_fn=None):
     """Infinite class-balanced batch generator: yields (batchData, labels).
     rank / world (default: the torch.distributed process group, else one process): this rank's rows
-    shard_indices(n_rows, rank, world) of every GLOBAL batch -- batchSize stays the global per-class batch size.
+    sharding.class_block_rows(n_classes, batchSize, rank, world) of every GLOBAL batch -- the same contiguous range of every class
+    block; batchSize stays the global per-class batch size.  On the device path a rank runs the front end only for the files its
+    rows come from (SURVEY 8e "Partitioning": shard per audio clip), decided from the files' patch counts before any kernel runs.
+    count_fn(spec) / batch_patches_fn(specs): injection points of the device path for tests (patch count of a file from its length;
+    the patches of a list of files as one batch) -- defaults: the integer contracts of libsmh and ONE ragged front-end pass.
 
     batchData: [batchSize music | batchSize speech | batchSize speech+music] patches, (3*batchSize, W, 2F) for the TCN
     models ((.., 2F, W, 1) for the Conv2D ones when the per-file callables are injected); labels: {'R', 'S', 'M', '3C'} for
@@ -252,8 +329,12 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
     if PARAMS.get('frame_level_scaling') or PARAMS.get('skewness_vector'):
         raise ValueError("frame_level_scaling / skewness_vector are off in every reference configuration of this path "
                          "(Proposed_Work_Results.py:802-804) and are not wired into the generator")
-    from .sharding import shard_indices
+    from .sharding import class_block_rows, shard_range
     rank, world, dist = _rank_world(rank, world)
+    if world > int(batchSize):
+        raise ValueError("batchSize = %d rows per class cannot be shared out between %d ranks" % (batchSize, world))
+    # this rank's rows of every class block: the same contiguous range [lo, hi) of the class's batchSize rows
+    lo, hi = shard_range(int(batchSize), rank, world)
     per_file = featuregram_fn is not None or patches_fn is not None
     if per_file:
         from .lib import preprocessing as pp
@@ -262,6 +343,8 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
     lengths = {}
     buf = {'speech': _ClassBuffer(), 'music': _ClassBuffer(), 'speech_music': _ClassBuffer()}
     rng = np.random  # the reference draws from numpy's global state
+    count_fn = count_fn or (lambda spec: _n_patches_of_spec(PARAMS, spec, n_fft, n_mels, W, W_shift, lengths))
+    batch_patches_fn = batch_patches_fn or (lambda specs: _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, W_shift))
 
     def one_file(spec):
         classname, sp, mu, db = spec
@@ -269,28 +352,34 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
         return patches_fn(PARAMS, fv, W, W_shift, featName)
 
     def fill(classname, next_spec):
-        """Pop files until the class buffer holds a batch (the reference's `while balance < batchSize` loops)."""
+        """Pop files until the class queue holds a batch (the reference's `while balance < batchSize` loops).  With the per-file
+        callables a file's patches are computed as it is popped; on the device path only its patch COUNT is needed here -- an
+        integer contract of its length -- and `compute` below runs the front end for the files this rank's rows come from."""
         b = buf[classname]
-        if per_file:
-            while b.balance < batchSize:
-                spec = next_spec()
-                if spec is None:
-                    continue
-                b.add(one_file(spec), spec[3])
-            return
-        specs, predicted = [], b.balance
-        while predicted < batchSize:
+        while b.balance < batchSize:
             spec = next_spec()
             if spec is None:
                 continue
-            # a mixture has the length of its speech file: the music is looped / cut to it (preprocessing.py:303-310)
-            n = _n_patches_of_file(PARAMS, spec[2] if classname == 'music' else spec[1], n_fft, W, W_shift, lengths)
-            specs.append(spec)
-            predicted += n
-        for spec, patches in zip(specs, _device_patches_for(PARAMS, specs, featName, n_fft, n_mels, W, W_shift)):
-            b.add(patches, spec[3])
-        if b.balance < batchSize:  # a cached featuregram was shorter than its file predicted: top up file by file
-            fill(classname, next_spec)
+            if per_file:
+                b.add(spec, spec[3], 0, one_file(spec))
+            else:
+                b.add(spec, spec[3], count_fn(spec))
+
+    def compute(classes_, next_of):
+        """The front end for every file this rank's rows [lo, hi) of each class block come from and that has no patches yet: ONE
+        ragged device batch for the whole global batch's share.  In a single process a file that turns out shorter than promised
+        (a stale cache file) makes the class top itself up; under data parallel that is an error -- the ranks pop files by count."""
+        while True:
+            todo = [(c, f) for c in classes_ for f in buf[c].pending(lo, hi)]
+            if not todo:
+                return
+            for (c, f), patches in zip(todo, batch_patches_fn([f[0] for _, f in todo])):
+                buf[c].set_patches(f, patches, strict=world > 1)
+            short = [c for c in classes_ if buf[c].balance < batchSize]
+            if not short:
+                return
+            for c in short:
+                fill(c, next_of[c])
 
     def next_speech():
         nonlocal file_list_sp_temp
@@ -315,34 +404,40 @@ def generator(PARAMS, folder, file_list, batchSize, featuregram_fn=None, patches
         sp, mu = folder + '/speech/' + info['speech'], folder + '/music/' + info['music']
         return ('speech_music', sp, mu, info['SMR']) if (os.path.exists(sp) and os.path.exists(mu)) else None
 
+    next_of = {'speech': next_speech, 'music': next_music, 'speech_music': next_mix if three else None}
+    classes_ = ['music', 'speech'] + (['speech_music'] if three else [])
+    mine = class_block_rows(len(classes_), int(batchSize), rank, world) if world > 1 else None
     while 1:
         fill('speech', next_speech)
         fill('music', next_music)
-        data_mu, _ = buf['music'].take(batchSize)
-        data_sp, _ = buf['speech'].take(batchSize)
+        if three:
+            fill('speech_music', next_mix)
+        if not per_file:
+            compute(classes_, next_of)
+        data_mu, _ = buf['music'].take(batchSize, lo, hi)
+        data_sp, _ = buf['speech'].take(batchSize, lo, hi)
         parts = [data_mu, data_sp]
         smr = None
         if three:
-            fill('speech_music', next_mix)
-            data_mix, smr = buf['speech_music'].take(batchSize)
+            data_mix, smr = buf['speech_music'].take(batchSize, lo, hi)
             parts.append(data_mix)
         host_batch = isinstance(parts[0], np.ndarray)
-        mine = shard_indices(sum(int(p.shape[0]) for p in parts), rank, world) if world > 1 else None
         if host_batch:
-            batchData = np.concatenate(parts, axis=0)
-            if 'Lemaire_et_al' in PARAMS['Model']:
+            batchData = np.concatenate(parts, axis=0)  # this rank's rows [lo, hi) of every class block
+            if 'Lemaire_et_al' in PARAMS['Model'] and per_file:
                 batchData = np.transpose(batchData, axes=(0, 2, 1))  # per-file callables return (nP, F, W)
-            # host batches draw their noise from numpy's global state: augment the GLOBAL batch, then take this rank's rows,
-            # so that every rank consumes the same random numbers and the states stay in step
+            # host batches draw their noise from numpy's global state: the draw has the GLOBAL batch's shape on every rank (the
+            # ranks consume the same random numbers and their states stay in step) and a rank adds its rows of it
             if PARAMS['data_augmentation_with_noise']:
-                batchData = batching.noise_augmentation(batchData, rng)
-            if mine is not None:
-                batchData = batchData[mine]
+                if mine is None:
+                    batchData = batching.noise_augmentation(batchData, rng)
+                else:
+                    full = np.zeros((len(classes_) * int(batchSize),) + batchData.shape[1:], batchData.dtype)
+                    full[mine] = batchData
+                    batchData = batching.noise_augmentation(full, rng)[mine]
         else:
             import torch
             batchData = torch.cat(parts, dim=0)  # device patches are already (N, W, F)
-            if mine is not None:
-                batchData = batchData[torch.as_tensor(mine, device=batchData.device)]
             if PARAMS['data_augmentation_with_noise']:  # the scale from numpy (same on all ranks), the noise from torch's generator
                 batchData = batching.noise_augmentation(batchData, rng)
         if three:

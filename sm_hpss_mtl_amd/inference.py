@@ -133,4 +133,7 @@ def patch_probabilities(fv, model, W, W_shift=1, output="M", batch_frames=10000)
         preds.append(model.forward_device(x)[:, col])
     if not preds:
         return np.zeros((0,), np.float32)
-    return torch.cat(preds).cpu().numpy()
+    out = torch.cat(preds)
+    if hasattr(model, "check_status"):
+        model.check_status()  # the forwards above only enqueued work: a device-side give-up raises here, before the track leaves
+    return out.cpu().numpy()

@@ -28,7 +28,10 @@ def _free_port() -> int:
 KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
 
 
-def visible_gpus(kfd_nodes: str = KFD_NODES) -> int:
+DRI_DIR = "/dev/dri"
+
+
+def visible_gpus(kfd_nodes: str = KFD_NODES, dri_dir=None) -> int:
     """Number of GPUs this process would see, WITHOUT loading torch or any HIP / HSA library: the parent of the ranks must never
     initialise the GPU, and `torch.cuda.device_count()` falls back to hipGetDeviceCount when amdsmi is not importable.
     Counts the KFD topology nodes that have SIMDs (CPU nodes have none), then applies the ROCR / HIP / CUDA visibility lists the
@@ -45,10 +48,38 @@ def visible_gpus(kfd_nodes: str = KFD_NODES) -> int:
                 continue
     except OSError:
         return 0
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    # Visibility lists, applied the way the runtimes apply them: ROCR filters the KFD nodes, HIP / CUDA then index what ROCR left;
+    # a list ends at its first entry that is not a valid, not yet used index (the runtime ignores everything from there on).
+    # Approximations that remain: UUID entries ("GPU-...") count as valid, cgroup device rules are not read; /dev/dri/renderD*
+    # permissions are checked below.
+    def keep(count, var):
         v = os.environ.get(var)
-        if v is not None:
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+        if v is None:
+            return count
+        seen, kept = set(), 0
+        for x in v.split(","):
+            x = x.strip()
+            if x.upper().startswith("GPU-"):
+                kept += 1
+                continue
+            if not x.lstrip("-").isdigit() or int(x) < 0 or int(x) >= count or int(x) in seen:
+                break
+            seen.add(int(x))
+            kept += 1
+        return min(count, kept)
+
+    n = keep(n, "ROCR_VISIBLE_DEVICES")
+    n = keep(n, "HIP_VISIBLE_DEVICES")
+    n = keep(n, "CUDA_VISIBLE_DEVICES")
+    # a rank also needs its render node: count the readable ones when the directory exists (containers that hide them show fewer)
+    if dri_dir is None and kfd_nodes == KFD_NODES:
+        dri_dir = DRI_DIR
+    try:
+        nodes = [d for d in os.listdir(dri_dir) if d.startswith("renderD")] if dri_dir else []
+        if nodes:
+            n = min(n, sum(1 for d in nodes if os.access(os.path.join(dri_dir, d), os.R_OK | os.W_OK)))
+    except OSError:
+        pass
     return n
 
 

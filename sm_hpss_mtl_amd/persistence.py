@@ -283,6 +283,9 @@ class HeadModel:
     def _train_step_raw(self, bx, by):
         return self.train_on_batch(bx, by, sync=False)
 
+    def _check_device_status(self):
+        self.model.check_status()  # the parent model's device error word (the sub-model runs the parent's kernels)
+
     def fit(self, *args, **kwargs):
         """fit(generator | arrays, ..., callbacks=[...]): the loop of TrainingMixin.fit on the single-output sub-model."""
         from .training import TrainingMixin

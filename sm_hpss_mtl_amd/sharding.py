@@ -22,6 +22,16 @@ def shard_range(n_clips: int, rank: int, world: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def class_block_rows(n_classes: int, per_class: int, rank: int, world: int) -> np.ndarray:
+    """Rows of rank `rank` in a class-balanced batch [per_class rows of class 0 | per_class of class 1 | ...]: the SAME contiguous
+    range shard_range(per_class, rank, world) of every class block.  Contiguous, so that the files feeding a rank's rows are a
+    contiguous run of the files the batch was built from (generators.generator runs the front end only for those); the same
+    range in every class, so that every rank holds every class in equal numbers."""
+    lo, hi = shard_range(per_class, rank, world)
+    return np.concatenate([np.arange(c * per_class + lo, c * per_class + hi, dtype=np.int64) for c in range(n_classes)]) \
+        if n_classes > 0 else np.zeros(0, np.int64)
+
+
 def gather_rows(local, indices, n_total, dist=None):
     """Reassemble per-clip rows computed on each rank into global clip order on every rank
     (reporting only).  `local` is a (n_local, d) tensor for `indices` (global clip ids)."""

@@ -308,7 +308,10 @@ class TrainingMixin:
                                                p(losses), _cur_stream()), "smh_train_step_f32")
         if apply:
             self.apply_gradients(_mask)
-        return self.losses_to_list(losses) if sync else losses
+        if not sync:
+            return losses
+        self._check_device_status()  # the step's forward may have given up on the device: never report its losses as a step
+        return self.losses_to_list(losses)
 
     def _apply_native(self, lr, scale, mask):
         o = self.optimizer
@@ -453,6 +456,11 @@ class TrainingMixin:
         self.check_status()  # one synchronisation for the whole pass; a device-side give-up raises here
         return sums.cpu().numpy(), cnt  # already in metrics order: [loss, <per-output losses>, 3C_accuracy]
 
+    def _check_device_status(self):
+        """Raise if a kernel of this model set the device error word (B3_MTL: smh_model_status); models without one: nothing."""
+        if hasattr(self, "check_status"):
+            self.check_status()
+
     # ---- fit ------------------------------------------------------------------------------------------
     def _train_step_raw(self, bx, by):
         return self.train_on_batch(bx, by, sync=False)
@@ -519,6 +527,11 @@ class TrainingMixin:
             t0 = time.time()
             acc = None  # device-side sum of the raw per-step losses: one read-back per epoch
             pending = None
+            if side is not None:
+                # whatever the main stream did with the generator's shared state since the last fetch (validation generator, a
+                # callback running the front end on a file: the cached Frontend's workspace, the device featuregram cache) is
+                # ordered before this epoch's first side-stream fetch
+                side.wait_stream(torch.cuda.current_stream())
             for s in range(int(steps_per_epoch)):
                 if arrays:
                     sl = slice((s * bs) % len(xs), (s * bs) % len(xs) + bs)
@@ -540,6 +553,7 @@ class TrainingMixin:
                 dist.all_reduce(mean_raw, op=dist.ReduceOp.SUM)
                 mean_raw = mean_raw / float(world)
             mean = self.losses_to_list(mean_raw)
+            self._check_device_status()  # once per epoch, where the losses are read back anyway (the steps only enqueued work)
             logs = {n: float(v) for n, v in zip(names, mean)}
             if validation_data is not None:
                 if isinstance(validation_data, (tuple, list)) and not hasattr(validation_data, "__next__"):

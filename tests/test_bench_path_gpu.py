@@ -18,6 +18,15 @@ import torch
 from oracle import b3_mtl, frontend as ofe
 
 pytestmark = pytest.mark.gpu
+
+
+def _skip_if_forced(*names):
+    """Tests that assert WHICH implementation the bench path took are skipped, not failed, when an environment switch forces another
+    one (tools/gpu/r*_variants.sh)."""
+    import os
+    forced = [n for n in names if os.environ.get(n)]
+    if forced:
+        pytest.skip("implementation forced by " + ", ".join(forced))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = 1024
 SPREAD = (0, 1, 63, 64, 511, 700, 1022, 1023)  # clips spread over the batch (and over the workgroups of every kernel)
@@ -45,6 +54,7 @@ def test_timed_median_variant_is_bit_exact_at_bench_size(lh, lp, persist, monkey
     the headline number is measured on: every one of the 1024 clips against the oracle, bit for bit."""
     if persist is not None:
         monkeypatch.setenv("SMH_MEDIAN_PERSIST", persist)
+    _skip_if_forced("SMH_FEAT_TWO_KERNELS", "SMH_FEAT_TAPS", "SMH_MEDIAN_NOSPLIT")
     hp, _ = _hot_path(lh, lp)
     base, audio = _bench_audio()
     hp.step(audio)
@@ -61,6 +71,7 @@ def test_timed_median_variant_is_bit_exact_at_bench_size(lh, lp, persist, monkey
 def test_timed_feature_kernel_vs_oracle_from_device_S(lh, lp):
     """features_clip_kernel as bench.py launches it (blocked harm, layer-0 partials, no patches): the featuregram it
     writes against the oracle started from the device's OWN S -- abs 1e-3 dB on 100 % of the bins."""
+    _skip_if_forced("SMH_FEAT_TWO_KERNELS", "SMH_FEAT_TAPS", "SMH_MEDIAN_NOSPLIT")
     hp, _ = _hot_path(lh, lp)
     base, audio = _bench_audio()
     hp.step(audio)

@@ -154,7 +154,7 @@ def test_array_batches_are_shared_out_between_the_ranks():
 # ---- the generator's ranks build one global batch and take their rows of it ------------------------------------------------
 from tests.test_generators import _files, _fv, _params, _patches  # noqa: E402  (the stand-in files / per-file callables)
 from sm_hpss_mtl_amd import generators as gen  # noqa: E402
-from sm_hpss_mtl_amd.sharding import shard_indices  # noqa: E402
+from sm_hpss_mtl_amd.sharding import class_block_rows  # noqa: E402
 
 
 @pytest.mark.parametrize("noise", [False, True])
@@ -179,20 +179,70 @@ def test_union_of_the_ranks_rows_is_the_single_process_batch(tmp_path, noise, wo
         lab = {k: np.empty_like(v) for k, v in lab_ref.items()}
         seen = np.zeros(n, bool)
         for r in range(world):
-            idx = shard_indices(n, r, world)
+            idx = class_block_rows(3, bs, r, world)   # the same contiguous range of every class block
             xr, lr = per_rank[r][b]
             assert xr.shape[0] == len(idx) and not seen[idx].any()
             seen[idx] = True
             x[idx] = xr
             for k in lab:
                 lab[k][idx] = lr[k]
-            # the global batch is [bs music | bs speech | bs mixtures]: a rank's rows hold every class (balance is global, and
-            # round-robin rows keep it per rank up to one row)
+            # the global batch is [bs music | bs speech | bs mixtures]: a rank's rows hold every class in equal numbers
             counts = lr["3C"].sum(0)
-            assert counts.max() - counts.min() <= 1
+            assert counts.max() == counts.min()
         assert seen.all() and np.array_equal(x, x_ref)
         for k in lab:
             assert np.array_equal(lab[k], lab_ref[k]), k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_runs_the_front_end_only_for_the_files_its_rows_come_from(tmp_path, world):
+    """The device path of the generator (stood in for by `batch_patches_fn`, which records what it is asked for): the files of a
+    global batch are decided from their patch counts, and rank r sends through the front end only the files its rows [lo, hi) of
+    every class block come from -- about 1/world of them (a file that straddles two ranks' ranges, or two batches, is computed by
+    both) -- while the union of the ranks' rows still IS the single-process batch, and all ranks pop the same files."""
+    P = _params(tmp_path, False)
+    folder, files = _files(tmp_path)
+    bs, n_batches = 12, 8
+
+    def count(spec):
+        return _patches(P, _fv(P, spec[0], "", spec[1], spec[2], spec[3], 400, 120, "x"), P["W"], P["W_shift"], "x").shape[0]
+
+    def make(log):
+        def batch(specs):
+            log.append([s[1] + "|" + s[2] for s in specs])
+            return [np.transpose(_patches(P, _fv(P, s[0], "", s[1], s[2], s[3], 400, 120, "x"), P["W"], P["W_shift"], "x"), (0, 2, 1))
+                    for s in specs]
+        return batch
+
+    logs = [[] for _ in range(world + 1)]
+    np.random.seed(77)
+    single = gen.generator(P, folder, copy.deepcopy(files), bs, count_fn=count, batch_patches_fn=make(logs[world]))
+    ref = [next(single) for _ in range(n_batches)]
+    state_after = np.random.get_state()[1].copy()
+    per_rank = []
+    for r in range(world):
+        np.random.seed(77)
+        g = gen.generator(P, folder, copy.deepcopy(files), bs, count_fn=count, batch_patches_fn=make(logs[r]), rank=r, world=world)
+        per_rank.append([next(g) for _ in range(n_batches)])
+        assert np.array_equal(np.random.get_state()[1], state_after)  # every rank consumed numpy's state like the single process
+    for b in range(n_batches):
+        x_ref, lab_ref = ref[b]
+        x = np.full_like(x_ref, np.nan)
+        for r in range(world):
+            idx = class_block_rows(3, bs, r, world)
+            x[idx] = per_rank[r][b][0]
+            for k in lab_ref:
+                assert np.array_equal(per_rank[r][b][1][k], lab_ref[k][idx]), k
+        assert np.array_equal(x, x_ref)
+    n_single = sum(len(c) for c in logs[world])
+    n_rank = [sum(len(c) for c in logs[r]) for r in range(world)]
+    assert len(logs[world]) == n_batches or len(logs[world]) <= n_batches   # one front-end call per batch at most
+    # every file the single process computed was computed by somebody, nobody computed anything else
+    assert set(f for c in logs[world] for f in c) == set(f for r in range(world) for c in logs[r] for f in c)
+    # ~ 1 / world each: a rank's share of the files plus the few that straddle a range or a batch boundary
+    for n in n_rank:
+        assert n <= n_single / world + 2 * n_batches * 3 / world + 3, (n_rank, n_single)
+    assert sum(n_rank) < 1.6 * n_single, (n_rank, n_single)
 
 
 def _gen_worker(rank, world, port, tmp, same_seed, q):

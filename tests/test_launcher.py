@@ -70,6 +70,23 @@ def test_gpu_count_of_the_parent_reads_the_kfd_topology_only(tmp_path, monkeypat
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
     assert launch.visible_gpus(str(tmp_path)) == 2
     assert launch.visible_gpus(str(tmp_path / "missing")) == 0
+    # a list ends at its first invalid or repeated index, as in the runtime; HIP indexes what ROCR left
+    for hip, want in (("0,0,1", 1), ("1,7,2", 1), ("5", 0), ("", 0), ("2,1,0", 3), ("0,x,1", 1), ("-1", 0)):
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", hip)
+        assert launch.visible_gpus(str(tmp_path)) == want, hip
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,2")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")   # index 2 does not exist among the two nodes ROCR left
+    assert launch.visible_gpus(str(tmp_path)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert launch.visible_gpus(str(tmp_path)) == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # render nodes the process cannot open do not count
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    for i in (128, 129):
+        (dri / ("renderD%d" % i)).write_text("")
+    assert launch.visible_gpus(str(tmp_path), str(dri)) == 2
 
 
 def test_nccl_parent_maps_no_gpu_runtime():

@@ -11,6 +11,15 @@ from tests.conftest import checks
 pytestmark = pytest.mark.gpu
 
 
+def _skip_if_forced(*names):
+    """A test that asserts WHICH implementation ran (not what it computed) has nothing to say when an environment switch forces
+    another one (tools/gpu/r*_variants.sh run the suites under such switches): skipped there, not failed."""
+    import os
+    forced = [n for n in names if os.environ.get(n)]
+    if forced:
+        pytest.skip("implementation forced by " + ", ".join(forced))
+
+
 @pytest.fixture(scope="module")
 def fe():
     from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
@@ -384,7 +393,9 @@ def test_b3mtl_block_schedules_agree(W, N, monkeypatch):
     outs = {}
     # 2: the skew schedule whenever it can run (by default only where it is the faster one); "16": its 16-wave form with the
     # block weights in an LDS ring instead of registers (opt-in, SMH_TCN_SKEW16=1)
-    for skew in ("2", "0", "16"):
+    # (the 16-wave form only exists in a lab build of the library: python -m sm_hpss_mtl_amd.build --lab)
+    variants = ("2", "0", "16") if m.lib.smh_internal_lab() else ("2", "0")
+    for skew in variants:
         monkeypatch.setenv("SMH_TCN_SKEW", "2" if skew == "16" else skew)
         monkeypatch.setenv("SMH_TCN_SKEW16", "1" if skew == "16" else "0")
         trunk = torch.empty((N, W, 32), device="cuda")
@@ -393,7 +404,8 @@ def test_b3mtl_block_schedules_agree(W, N, monkeypatch):
     # bit for bit: all add the same products in the same order (centre tap first), so a patch's outputs do not depend on the
     # schedule its batch size selects
     assert np.array_equal(outs["2"][0], outs["0"][0]) and np.array_equal(outs["2"][1], outs["0"][1])
-    assert np.array_equal(outs["16"][0], outs["0"][0]) and np.array_equal(outs["16"][1], outs["0"][1])
+    if "16" in outs:
+        assert np.array_equal(outs["16"][0], outs["0"][0]) and np.array_equal(outs["16"][1], outs["0"][1])
     # the barrier schedule gives a lone last-round tile to two waves, 16 output channels each (5, 9, 13, 17 tiles): without the
     # split (SMH_TCN_SPLIT=0) the same bits
     monkeypatch.setenv("SMH_TCN_SKEW", "0")
@@ -434,6 +446,25 @@ def test_skew_give_up_is_reported(monkeypatch):
     monkeypatch.delenv("SMH_ENABLE_PROBES")
     after = m.predict(x)
     assert all(np.array_equal(a, b) for a, b in zip(good, after))
+    # the same contract on the other entries that only enqueue a forward: dense file-level inference (patch_probabilities) and the
+    # training step (train_on_batch(sync=True); fit checks once per epoch where it reads the losses back)
+    from sm_hpss_mtl_amd import inference
+    fv = np.random.default_rng(4).standard_normal((240, 700)).astype(np.float32)
+    track = inference.patch_probabilities(fv, m, 68, 1, "M")
+    rng = np.random.default_rng(6)
+    y = {"S": rng.integers(0, 2, (64, 1)).astype(np.float32), "M": rng.integers(0, 2, (64, 1)).astype(np.float32),
+         "R": rng.random((64, 2)).astype(np.float32), "3C": np.eye(3, dtype=np.float32)[rng.integers(0, 3, 64)]}
+    losses = m.train_on_batch(x, y, apply=False)
+    assert np.isfinite(losses).all()
+    monkeypatch.setenv("SMH_TCN_TUNE", "256")
+    monkeypatch.setenv("SMH_ENABLE_PROBES", "1")
+    with pytest.raises(RuntimeError, match="gave up"):
+        inference.patch_probabilities(fv, m, 68, 1, "M")
+    with pytest.raises(RuntimeError, match="gave up"):
+        m.train_on_batch(x, y, apply=False)
+    monkeypatch.delenv("SMH_TCN_TUNE")
+    monkeypatch.delenv("SMH_ENABLE_PROBES")
+    assert np.array_equal(inference.patch_probabilities(fv, m, 68, 1, "M"), track)
 
 
 def test_get_lemaire_model_surface(tmp_path):
@@ -561,6 +592,7 @@ def test_single_feature_kernel_on_blocked_harm_matches_the_two_step_path(fe, cli
     harm0, perc0 = fe.hpss_median(S)
     two = fe.features(S, harm0, perc0, W=W, shift=shift)
     ref = m.forward_device(two["patches"])
+    _skip_if_forced("SMH_FEAT_TWO_KERNELS", "SMH_FEAT_TAPS", "SMH_MEDIAN_NOSPLIT")
     assert fe.lib.smh_features_blocked_ok(fe._h, T, 1) == 1
     harm2 = torch.empty((B, fe.lib.smh_harm_buffer_floats(K, T)), device="cuda")
     perc2 = torch.empty_like(S)
