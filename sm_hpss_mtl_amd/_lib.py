@@ -123,6 +123,7 @@ SIGNATURES = {
     "smh_trainer_copy_state": (_i, [_vp, _vp, _vp]),
     "smh_trainer_reset_state": (_i, [_vp, _vp]),
     "smh_trainer_set_deterministic": (_i, [_vp, _i, _vp]),
+    "smh_trainer_set_dtype": (_i, [_vp, _i]),
     "smh_trainer_apply_f32": (_i, [_vp, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint, _vp]),
 }
 

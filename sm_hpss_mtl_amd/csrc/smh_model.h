@@ -97,6 +97,7 @@ struct Offsets {
 Offsets offsets(const smh_model *m);
 void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
 int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
+int launch_forward_bf16_train(smh_model *m, const float *d_x, int N, const TrainIO *tio, hipStream_t st);  // smh_tcn_bf16.hip
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
                    hipStream_t st, int from_x0 = 0, int x0_shift = 0, int x0_T = 0);
 // smh_model_cfg.block_variant = 1 (smh_tcn_v2.hip): the two-convolution residual block of keras-tcn >= 2.8, inference only

@@ -504,10 +504,16 @@ __device__ __forceinline__ float quad_max_s(float v) {
 // NT = 1 or 2 column tiles of one block as ONE straight-line region: with two tiles the compiler interleaves their independent
 // chains (LDS reads -> 18 dependent products -> channel maximum -> 6 products -> stores), which a wave alone cannot overlap -- a
 // tile's critical path is about twice its issue time.  Split images (xh, xl) of the block's input -> (yh, yl), residual image in place.
-template <int NT>
-__device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int ZR, const int *R, const int *Rc, const int *t, int q,
-                                            const __bf16 *__restrict__ xh, const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh,
-                                            __bf16 *__restrict__ yl, f32x4 *res0, f32x4 *res1) {
+// what the TRAINING forward saves / applies per block (smh_model.h: TrainIO), for this workgroup's first patch
+struct TrainBlk {
+    float *upre;        // this block's slice of the saved dilated-conv outputs (incl. bias, before the relu), patch stride ustride
+    const float *drop;  // this block's SpatialDropout1D mask of the first patch (32 channels), patch stride dstride; or nullptr
+    int ustride, dstride, GR;
+};
+template <int NT, bool TRAIN>
+__device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int ZR, const int *R, const int *Rc, const int *t, const int *g,
+                                            int q, const __bf16 *__restrict__ xh, const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh,
+                                            __bf16 *__restrict__ yl, f32x4 *res0, f32x4 *res1, const TrainBlk &tb) {
     f32x4 acc0[NT], acc1[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) acc0[k] = w.b1lo, acc1[k] = w.b1hi;
@@ -537,6 +543,13 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
     bf16x8 nh[NT], nl[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
+        if constexpr (TRAIN) {  // the backward's relu / channel-max gates: the conv output as this forward computed it
+            if (tb.upre && R[k] < tb.GR) {
+                const unsigned uo = (unsigned)(g[k] * tb.ustride + t[k] * C + 4 * q);
+                *reinterpret_cast<f32x4 *>(tb.upre + uo) = acc0[k];
+                *reinterpret_cast<f32x4 *>(tb.upre + uo + 16) = acc1[k];
+            }
+        }
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -548,6 +561,13 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
         const float inv = __builtin_amdgcn_rcpf(mx + kNormEps);
         acc0[k] *= inv;
         acc1[k] *= inv;
+        if constexpr (TRAIN) {
+            if (tb.drop) {  // SpatialDropout1D: one mask value per (patch, channel)
+                const unsigned dofs = (unsigned)(g[k] * tb.dstride + 4 * q);
+                acc0[k] *= *reinterpret_cast<const f32x4 *>(tb.drop + dofs);
+                acc1[k] *= *reinterpret_cast<const f32x4 *>(tb.drop + dofs + 16);
+            }
+        }
         split8(acc0[k], acc1[k], nh[k], nl[k]);  // k' order = the order the 1x1 operand was packed in
     }
 #pragma unroll
@@ -569,24 +589,29 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
 // with up to four tiles each.
 template <int MAXT>
 struct TilesS {
-    int n, R[MAXT], Rc[MAXT], t[MAXT];
+    int n, R[MAXT], Rc[MAXT], t[MAXT], g[MAXT];
     f32x4 r0[MAXT], r1[MAXT];  // the residual stream of this lane's rows: channels 4q + r and 16 + 4q + r
 };
-template <int kMaxTilesS>
+template <int kMaxTilesS, bool TRAIN>
 __device__ __forceinline__ void run_block_split(const SplitW &w, int d, int T, int ZR, TilesS<kMaxTilesS> &ti, int q,
                                                 const __bf16 *__restrict__ xh, const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh,
-                                                __bf16 *__restrict__ yl) {
+                                                __bf16 *__restrict__ yl, const TrainBlk &tb) {
 #pragma unroll
     for (int i = 0; i < kMaxTilesS; i += 2) {
-        if (i + 1 < ti.n) tiles_split<2>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i);
-        else if (i < ti.n) tiles_split<1>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i);
+        if (i + 1 < ti.n)
+            tiles_split<2, TRAIN>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
+        else if (i < ti.n)
+            tiles_split<1, TRAIN>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
     }
 }
 
-template <int kMaxTilesS>
+// TRAIN: the training-mode forward (smh_train_step_f32 with the trainer's dtype set to bf16): saves every block's input and its
+// dilated-conv output for the backward pass -- straight from the lanes' registers --, applies the SpatialDropout1D masks, and
+// hands the Dense-on-trunk outputs to heads_train_kernel instead of running the inference heads (smh_model.h: TrainIO).
+template <int kMaxTilesS, bool TRAIN>
 __global__ void __launch_bounds__(kMaxTilesS == 2 ? 768 : 512)
 b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__restrict__ X, const float *__restrict__ flat,
-                           const bf16x8 *__restrict__ pk, const float *__restrict__ hp, float *__restrict__ out) {
+                           const bf16x8 *__restrict__ pk, const float *__restrict__ hp, float *__restrict__ out, TrainIO tio) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int q = lane >> 4, j = lane & 15;
@@ -623,9 +648,22 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
     for (int i = 0; i < kMaxTilesS; ++i) {
         const int u = wave + i * nw;
         const int R = 16 * u + j, Rc = min(R, GR - 1);
-        ti.R[i] = R, ti.Rc[i] = Rc, ti.t[i] = Rc % T;
+        ti.R[i] = R, ti.Rc[i] = Rc, ti.g[i] = Rc / T, ti.t[i] = Rc - ti.g[i] * T;
         if (u < units) ti.n = i + 1;
     }
+    const int nslot = a.n_blocks + 1;
+    auto save_acts = [&](int slot) {  // (training) the residual registers = block `slot`'s input -> acts[n][slot][t][c]
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int i = 0; i < kMaxTilesS; ++i) {
+                if (i < ti.n && ti.R[i] < GR) {
+                    float *dst = tio.acts + (((size_t)(n0 + ti.g[i]) * nslot + slot) * T + ti.t[i]) * C + 4 * q;
+                    *reinterpret_cast<f32x4 *>(dst) = ti.r0[i];
+                    *reinterpret_cast<f32x4 *>(dst + 16) = ti.r1[i];
+                }
+            }
+        }
+    };
 
     // ---- initial Conv1D(32, 1): into the residual registers and the split images of buffer 0 --------------------------------------
     if (a.from_x0) {
@@ -636,8 +674,7 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
         f32x4 pa[kMaxTilesS][4];
 #pragma unroll
         for (int i = 0; i < kMaxTilesS; ++i) {  // all loads first
-            const int g = ti.Rc[i] / T;
-            const float *p0 = X + ((((size_t)(n0 + g) * 2) * T + ti.t[i]) * C + 4 * q);
+            const float *p0 = X + ((((size_t)(n0 + ti.g[i]) * 2) * T + ti.t[i]) * C + 4 * q);
             const bool on = i < ti.n;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -716,11 +753,19 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
             __syncthreads();                                  // ... everybody's have, and block blk - 1 is complete in the images
             if (blk + 1 < a.n_blocks) stage(blk + 1);
             load_split_w(w, wslot + (size_t)(blk & 1) * 2 * kSlotOps, lane, q);
-            run_block_split(w, 1 << (blk % a.n_dil), T, ZR, ti, q, xh, xl, yh, yl);
+            TrainBlk tb{nullptr, nullptr, 0, 0, GR};
+            if constexpr (TRAIN) {
+                save_acts(blk);
+                tb.ustride = a.n_blocks * T * C, tb.dstride = a.n_blocks * C;
+                tb.upre = tio.upre ? tio.upre + (size_t)n0 * tb.ustride + (size_t)blk * T * C : nullptr;
+                tb.drop = tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * tb.dstride + (size_t)blk * C : nullptr;
+            }
+            run_block_split<kMaxTilesS, TRAIN>(w, 1 << (blk % a.n_dil), T, ZR, ti, q, xh, xl, yh, yl, tb);
             __bf16 *th = xh, *tl = xl;
             xh = yh, xl = yl, yh = th, yl = tl;
         }
     }
+    save_acts(a.n_blocks);  // (training) the pre-relu TCN output
     // final relu of the TCN output (f32, on the residual registers) -> split images of the Dense layers' input: over this lane's OWN
     // rows of the last block's output (nobody reads them before the barrier below; the other buffer may still be being read)
 #pragma unroll
@@ -784,6 +829,13 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
         return flat[off.head[h] + (size_t)a.D * kHidden + jj];
     };
     const int tid = threadIdx.x;
+    if constexpr (TRAIN) {  // training: the batch-statistics heads run in smh_train.hip on `pre` (incl. bias; padding columns zero)
+        for (int i = tid; i < g_here * kPS; i += blockDim.x) {
+            const int p = i / kPS, o = i - p * kPS;
+            tio.pre[(size_t)(n0 + p) * kPS + o] = o < a.NH ? pre[p * kPS + o] + bias_of(o) : 0.f;
+        }
+        return;
+    }
     if (tid < g_here * a.n_heads) {
         const int p = tid / a.n_heads, h = tid - p * a.n_heads;
         const float *ph = hp;
@@ -825,8 +877,10 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
 
 }  // namespace
 
-static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int split, int from_x0, void *stream) {
-    SMH_REQUIRE(m && d_x && d_out, "smh_model_forward_bf16: null argument");
+static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int split, int from_x0, void *stream,
+                        const TrainIO *tio = nullptr) {
+    SMH_REQUIRE(m && d_x && (d_out || tio), "smh_model_forward_bf16: null argument");
+    SMH_REQUIRE(!tio || split, "smh_model_forward_bf16: the training forward exists for split operands only");
     SMH_REQUIRE(N >= 0, "smh_model_forward_bf16: N=%d", N);
     SMH_REQUIRE(m->cfg.block_variant == 0, "smh_model_forward_bf16: built for block_variant 0 only");
     SMH_REQUIRE(m->cfg.n_feat <= 256, "smh_model_forward_bf16: n_feat=%d exceeds the 256 features of the bf16 layer-0 tiling",
@@ -861,15 +915,23 @@ static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int
         SMH_REQUIRE(lds_s <= 156 * 1024, "patch_size %d too long for the LDS-resident split-bf16 TCN", a.T);
         SMH_REQUIRE((size_t)pi.steps0 * 2 * 64 * 2 * 16 <= 2 * (size_t)(a.GRP + 1) * kRS * sizeof(__bf16) || from_x0,
                     "smh_model_forward_bf16: n_feat=%d too wide for the layer-0 operand staging", m->cfg.n_feat);
+        const TrainIO io = tio ? *tio : TrainIO{nullptr, nullptr, nullptr, nullptr};
+#define SMH_LAUNCH_BF16S(MT, TR)                                                                                                       \
+    do {                                                                                                                              \
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16s_kernel<MT, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds_s));                                                                               \
+        hipLaunchKernelGGL((b3mtl_forward_bf16s_kernel<MT, TR>), dim3((N + a.G - 1) / a.G), dim3(64 * nwaves_s), lds_s, st, a, pi, off,  \
+                           d_x, m->d_flat, (const bf16x8 *)m->d_bf16, m->d_hp, d_out, io);                                            \
+    } while (0)
         if (two) {
-            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16s_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-            hipLaunchKernelGGL(b3mtl_forward_bf16s_kernel<2>, dim3((N + a.G - 1) / a.G), dim3(64 * nwaves_s), lds_s, st, a, pi, off, d_x,
-                               m->d_flat, (const bf16x8 *)m->d_bf16, m->d_hp, d_out);
+            if (tio) SMH_LAUNCH_BF16S(2, true);
+            else SMH_LAUNCH_BF16S(2, false);
         } else {
-            SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16s_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-            hipLaunchKernelGGL(b3mtl_forward_bf16s_kernel<4>, dim3((N + a.G - 1) / a.G), dim3(64 * nwaves_s), lds_s, st, a, pi, off, d_x,
-                               m->d_flat, (const bf16x8 *)m->d_bf16, m->d_hp, d_out);
+            if (tio) SMH_LAUNCH_BF16S(4, true);
+            else SMH_LAUNCH_BF16S(4, false);
         }
+#undef SMH_LAUNCH_BF16S
+        return smh::launch_status("b3mtl_forward_bf16s_kernel");
     } else {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(b3mtl_forward_bf16_kernel<false>, dim3((N + a.G - 1) / a.G), dim3(512), lds, st, a, pi, off, d_x, m->d_flat,
@@ -877,6 +939,13 @@ static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int
     }
     return smh::launch_status("b3mtl_forward_bf16_kernel");
 }
+
+namespace smh_tcn {
+// the training-mode forward on split bf16 operands (smh_train_step_f32 when the trainer's dtype is bf16): same TrainIO as launch_forward
+int launch_forward_bf16_train(smh_model *m, const float *d_x, int N, const TrainIO *tio, hipStream_t st) {
+    return forward_bf16(m, d_x, N, nullptr, 1, 0, (void *)st, tio);
+}
+}  // namespace smh_tcn
 
 extern "C" int smh_model_forward_bf16_ex(smh_model *m, const float *d_x, int N, float *d_out, int split, void *stream) {
     return forward_bf16(m, d_x, N, d_out, split, 0, stream);

@@ -1265,6 +1265,7 @@ struct smh_trainer {
     float *d_upre = nullptr;  // (max_batch, n_blocks, T, 32): TrainIO::upre
     double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
     Segment *d_segs = nullptr;
+    int dtype = 0;             // smh_trainer_set_dtype: 0 = exact-f32 matrix products, 1 = split-bf16 operands (f32 accumulators, f32 master weights)
     long step = 0;             // optimiser steps taken (Adam / Nadam bias corrections)
     double m_schedule = 1.0;   // Nadam's running product of the momentum schedule
 };
@@ -1371,6 +1372,13 @@ extern "C" int smh_trainer_set_deterministic(smh_trainer *t, int on, void *strea
     return SMH_OK;
 }
 
+extern "C" int smh_trainer_set_dtype(smh_trainer *t, int dtype) {
+    SMH_REQUIRE(t, "smh_trainer_set_dtype: null trainer");
+    SMH_REQUIRE(dtype == 0 || dtype == 1, "smh_trainer_set_dtype: dtype must be 0 (f32) or 1 (split bf16 operands)");
+    t->dtype = dtype;
+    return SMH_OK;
+}
+
 extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float *d_y, int N, const float *d_drop_tcn,
                                   const float *d_drop_heads, const float *h_loss_weights, float *d_losses, void *stream) {
     SMH_REQUIRE(t && d_x && d_y && d_losses, "smh_train_step_f32: null argument");
@@ -1379,7 +1387,9 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     hipStream_t st = (hipStream_t)stream;
     SMH_CHECK_HIP(hipMemsetAsync(t->d_grad, 0, m->n_params * sizeof(float), st));
     TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre, t->d_upre};
-    int rc = launch_forward(m, d_x, N, t->d_scratch_out, nullptr, &tio, st);
+    // dtype 1: the training forward on the bf16 matrix pipe (split operands: f32-grade products, smh_tcn_bf16.hip); it saves the
+    // same activations and gates in f32, so the backward pass below is unchanged
+    int rc = t->dtype == 1 ? launch_forward_bf16_train(m, d_x, N, &tio, st) : launch_forward(m, d_x, N, t->d_scratch_out, nullptr, &tio, st);
     if (rc) return rc;
     const Offsets off = offsets(m);
     HeadsArgs ha;

@@ -207,6 +207,27 @@ class TrainingMixin:
 
     def _on_new_trainer(self):
         self._apply_deterministic()
+        self._apply_train_dtype()
+
+    def _apply_train_dtype(self):
+        if self._trainer is not None and self._TRAINER_API[0] == "smh_trainer_create":
+            _lib.check(self.lib.smh_trainer_set_dtype(self._trainer, 1 if getattr(self, "_train_dtype", "f32") == "bf16" else 0),
+                       "smh_trainer_set_dtype")
+
+    @property
+    def train_dtype(self):
+        """'f32' (default) or 'bf16': the training step's forward on the bf16 matrix pipe with split operands (f32-grade products,
+        f32 accumulators and master weights; include/smh.h: smh_trainer_set_dtype).  B3_MTL only."""
+        return getattr(self, "_train_dtype", "f32")
+
+    @train_dtype.setter
+    def train_dtype(self, dtype):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("train_dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+        if dtype == "bf16" and self._TRAINER_API[0] != "smh_trainer_create":
+            raise ValueError("train_dtype='bf16' exists for the B3_MTL trainer only")
+        self._train_dtype = dtype
+        self._apply_train_dtype()
 
     def _apply_deterministic(self):
         if self._trainer is not None and hasattr(self.lib, "smh_trainer_set_deterministic") and self._TRAINER_API[0] == "smh_trainer_create":

@@ -35,7 +35,7 @@ def _flat_to_dict(model, flat):
 @pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68),
                                       (3, 3, 99),    # DAFx12...:760 -- MFMA backward, T <= 128 instantiation
                                       (3, 2, 249)])  # Proposed_Work_Results.py:724 -- MFMA backward, T <= 256 instantiation (kernels read from global memory)
-@pytest.mark.parametrize("schedule", ["default", "skew", "dwh_valu"])
+@pytest.mark.parametrize("schedule", ["default", "skew", "dwh_valu", "bf16"])
 def test_gradients_and_losses_vs_oracle(ncls, N, W, schedule, monkeypatch):
     # schedule "skew": the training forward on the flag-synchronised task list (by default only large batches take it; it
     # writes the saved activations and applies the SpatialDropout1D masks from inside its tasks), SMH_TCN_SKEW=2 forces it
@@ -48,6 +48,9 @@ def test_gradients_and_losses_vs_oracle(ncls, N, W, schedule, monkeypatch):
     lw = {"S": 0.7, "R": 1.3}
     m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls, loss_weights=lw)
     m.set_weights_dict(w)
+    if schedule == "bf16":  # the training forward on split bf16 operands (smh_trainer_set_dtype): same tolerances as the f32 step
+        m.train_dtype = "bf16"
+        assert m.train_dtype == "bf16"
     heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
     got = m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda(),
                            apply=False)
@@ -69,7 +72,11 @@ def test_gradients_and_losses_vs_oracle(ncls, N, W, schedule, monkeypatch):
         # a bias in front of BatchNorm has an analytically zero gradient: what either side holds there is float rounding of a
         # sum of O(0.1) terms that cancel
         atol = 2e-5 if name.endswith("/dense/bias") else 1e-6
-        assert np.abs(gg - gref).max() <= 2e-3 * scale + atol, (name, np.abs(gg - gref).max(), scale)
+        # The network's gradient is discontinuous where a relu input is zero or two channels tie for the channel maximum: a forward
+        # that differs from the oracle's by a relative eps takes the other branch on a fraction ~ eps of the gates, and the gradient
+        # moves by ~ sqrt(eps) of its norm.  eps ~ 1e-7 (f32 forward): the 2e-3 below; eps ~ 1e-5 (split-bf16 forward): 2e-2.
+        rtol = 2e-2 if schedule == "bf16" else 2e-3
+        assert np.abs(gg - gref).max() <= rtol * scale + atol, (name, np.abs(gg - gref).max(), scale)
 
 
 def test_sgd_step_matches_oracle():
@@ -260,7 +267,8 @@ def test_data_parallel_step_equals_the_oracle_step_on_the_mean_gradient():
     assert diff > 1e-4
 
 
-@pytest.mark.parametrize("ncls,N,schedule", [(3, 510, "default"), (3, 512, "default"), (5, 510, "default"), (3, 510, "skew")])
+@pytest.mark.parametrize("ncls,N,schedule", [(3, 510, "default"), (3, 512, "default"), (5, 510, "default"), (3, 510, "skew"),
+                                             (3, 510, "bf16"), (5, 510, "bf16")])
 def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatch):
     """BASELINE config 4 trains with batch 512 (3 x 170 = 510 patches for the class-balanced 3-class batch; 5 x 102 = 510
     for 5 classes).  `heads_train_kernel` is ONE workgroup whose batch reductions loop over N, the backward kernels
@@ -271,6 +279,8 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
     w, x, y, drop_tcn, drop_heads = _problem(ncls, N, seed=21)
     m = B3MTL(n_feat=240, patch_size=68, n_classes=ncls)
     m.set_weights_dict(w)
+    if schedule == "bf16":  # BASELINE config 5's "mixed bf16 CNN": the training forward on split bf16 operands
+        m.train_dtype = "bf16"
     heads = [n for n, _, _ in b3_mtl.head_spec(ncls)]
     got = m.train_on_batch(x, y, drop_tcn=torch.from_numpy(drop_tcn).cuda(), drop_heads=torch.from_numpy(drop_heads).cuda(), apply=False)
     ref = tr.forward_backward(x, y, w, ncls, drop_tcn, {h: drop_heads[:, i] for i, h in enumerate(heads)})
@@ -291,8 +301,12 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
         # elements may move by a few 1e-3 of the tensor's maximum (measured: <= 2.6e-3 when the backward recomputed the gates with
         # its own summation order, <= 5.5e-3 now that it takes the gates the float32 forward actually used, TrainIO::upre).
         rel_l2 = np.linalg.norm(gg - gref) / max(np.linalg.norm(gref), 1e-12)
-        assert rel_l2 <= 2e-3 or name.endswith("/dense/bias"), (name, rel_l2)
-        assert np.abs(gg - gref).max() <= 1e-2 * scale + (2e-5 if name.endswith("/dense/bias") else 1e-6), (name, np.abs(gg - gref).max(), scale)
+        # (split-bf16 forward: its 1e-5 relative error flips ~ 100 x as many relu / channel-maximum gates as f32 rounding does; the
+        # gradient of the function it computes is exact, its distance from the float64 oracle's follows sqrt(forward error):
+        # measured 3.9e-3 / 7.6e-3 relative L2 on the first layer's kernel, 3- / 5-class)
+        tol_l2, tol_el = (3e-2, 5e-2) if schedule == "bf16" else (2e-3, 1e-2)  # (2.0e-2 on the 16 x 2176 kernel of one head: three of its 8160 relu gates)
+        assert rel_l2 <= tol_l2 or name.endswith("/dense/bias"), (name, rel_l2)
+        assert np.abs(gg - gref).max() <= tol_el * scale + (2e-5 if name.endswith("/dense/bias") else 1e-6), (name, np.abs(gg - gref).max(), scale)
     # batch statistics handed to the moving averages (behind the gradient in the data-parallel bucket)
     bn = m._bucket_tensor()[m.count_params():].cpu().numpy()
     for hi, h in enumerate(heads):

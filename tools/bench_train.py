@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="force the two-stream form at any batch size")
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible weight gradients (fixed-point integer atomics, "
                     "smh_trainer_set_deterministic) instead of float atomics: states what determinism costs per step")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: the training forward on split bf16 operands "
+                    "(smh_trainer_set_dtype; BASELINE config 5's \"mixed bf16 CNN\")")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal (SMH_DIST_BACKEND=gloo on a CPU box): no compute")
     args = ap.parse_args()
     from sm_hpss_mtl_amd.launch import init_ranks, spawn_ranks_if_needed, timed_region
@@ -65,6 +67,7 @@ def main():
     fe = Frontend(FrontendConfig(l_harm=21, l_perc=11))
     model = B3MTL(n_feat=240, patch_size=W, n_classes=args.classes, TR_STEPS=100, seed=0)  # same seed: identical replicas
     model.deterministic_gradients = bool(args.deterministic)
+    model.train_dtype = args.dtype
     audio = torch.from_numpy(synth_clips(B, seed=2000 + rank)).cuda()  # B distinct clips per rank
     smr = np.array([(-5, 0, 5, 10, 15, 20)[i % 6] for i in range(bs)], np.float64)
     lab = make_labels_3class(bs, smr) if args.classes == 3 else make_labels_5class(bs, smr, smr[::-1].copy())
