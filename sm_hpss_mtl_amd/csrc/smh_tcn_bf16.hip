@@ -477,12 +477,26 @@ __device__ __forceinline__ void load_split_w(SplitW &w, const bf16x8 *pk, int la
     w.b2hi = *reinterpret_cast<const f32x4 *>(b2 + 16 + 4 * q);
 }
 // eight f32 values (a lane's 4 + 4 channels in k' order) -> hi = bf16(x), lo = bf16(x - hi)
+// (pairs: one v_cvt_pk_bf16_f32 rounds two values; the pair's float images are a shift and a mask of the packed word -- written
+// element by element hipcc converted every hi value on its own, 12 conversions per call instead of 8)
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const bf16x2s h = __builtin_convertvector(f32x2s{x0, x1}, bf16x2s);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2s hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const bf16x2s l = __builtin_convertvector(f32x2s{x0, x1} - hf, bf16x2s);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, bf16x8 &hi, bf16x8 &lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = (__bf16)a[i], hi[4 + i] = (__bf16)b[i];
-        lo[i] = (__bf16)(a[i] - (float)hi[i]), lo[4 + i] = (__bf16)(b[i] - (float)hi[4 + i]);
-    }
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(a[0], a[1], h0, l0);
+    split2(a[2], a[3], h1, l1);
+    split2(b[0], b[1], h2, l2);
+    split2(b[2], b[3], h3, l3);
+    hi = __builtin_bit_cast(bf16x8, u32x4s{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(bf16x8, u32x4s{l0, l1, l2, l3});
 }
 __device__ __forceinline__ f32x4 product3(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 xl, f32x4 c) {
     c = mfma_bf16(wl, xh, c);  // small terms first
@@ -510,13 +524,23 @@ struct TrainBlk {
     const float *drop;  // this block's SpatialDropout1D mask of the first patch (32 channels), patch stride dstride; or nullptr
     int ustride, dstride, GR;
 };
+// ro / wo: this lane's element offsets into an image for row Rc (operand reads, taps add off * kRS) and row R (its own output);
+// zo: the same lane position in the all-zero row -- computed once per kernel, a tap is then one add, two compares and a select
+// ws: the block's operand slot in LDS ([hi 9 KB][lo 9 KB], load_split_w has the layout).  The A operands are read WHERE THEY ARE USED,
+// tap by tap behind that tap's B operands: LDS returns in order, so the first product waits for six reads, not for the 36 of a
+// whole block's operands up front (nine waves' worth of them kept every wave's first product 1.3 k cycles behind the barrier).
 template <int NT, bool TRAIN>
-__device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int ZR, const int *R, const int *Rc, const int *t, const int *g,
-                                            int q, const __bf16 *__restrict__ xh, const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh,
-                                            __bf16 *__restrict__ yl, f32x4 *res0, f32x4 *res1, const TrainBlk &tb) {
+__device__ __forceinline__ void tiles_split(const bf16x8 *ws, int lane, int d, int T, unsigned zo, const int *R, const unsigned *ro,
+                                            const unsigned *wo, const int *t, const int *g, int q, const __bf16 *__restrict__ xh,
+                                            const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh, __bf16 *__restrict__ yl, f32x4 *res0,
+                                            f32x4 *res1, const TrainBlk &tb) {
+    const float *bias = reinterpret_cast<const float *>(ws + 8 * 64);  // [b1 32 | b2 32]
     f32x4 acc0[NT], acc1[NT];
+    {
+        const f32x4 b1lo = *reinterpret_cast<const f32x4 *>(bias + 4 * q), b1hi = *reinterpret_cast<const f32x4 *>(bias + 16 + 4 * q);
 #pragma unroll
-    for (int k = 0; k < NT; ++k) acc0[k] = w.b1lo, acc1[k] = w.b1hi;
+        for (int k = 0; k < NT; ++k) acc0[k] = b1lo, acc1[k] = b1hi;
+    }
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
         const int off = (tap - 1) * d;
@@ -530,16 +554,20 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
         bf16x8 bh[NT], bl[NT];
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
-            const unsigned row = (unsigned)(ok[k] ? Rc[k] + off : ZR) * kRS + 8 * q;
+            const unsigned row = ok[k] ? ro[k] + (unsigned)(off * kRS) : zo;
             bh[k] = *reinterpret_cast<const bf16x8 *>(xh + row);
             bl[k] = *reinterpret_cast<const bf16x8 *>(xl + row);
         }
+        const bf16x8 c0h = ws[(2 * tap) * 64 + lane], c0l = ws[kSlotOps + (2 * tap) * 64 + lane];
+        const bf16x8 c1h = ws[(2 * tap + 1) * 64 + lane], c1l = ws[kSlotOps + (2 * tap + 1) * 64 + lane];
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
-            acc0[k] = product3(w.ch[tap][0], w.cl[tap][0], bh[k], bl[k], acc0[k]);
-            acc1[k] = product3(w.ch[tap][1], w.cl[tap][1], bh[k], bl[k], acc1[k]);
+            acc0[k] = product3(c0h, c0l, bh[k], bl[k], acc0[k]);
+            acc1[k] = product3(c1h, c1l, bh[k], bl[k], acc1[k]);
         }
     }
+    const bf16x8 p0h = ws[6 * 64 + lane], p0l = ws[kSlotOps + 6 * 64 + lane], p1h = ws[7 * 64 + lane], p1l = ws[kSlotOps + 7 * 64 + lane];
+    const f32x4 b2lo = *reinterpret_cast<const f32x4 *>(bias + C + 4 * q), b2hi = *reinterpret_cast<const f32x4 *>(bias + C + 16 + 4 * q);
     bf16x8 nh[NT], nl[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
@@ -572,14 +600,14 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
     }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        f32x4 o0 = res0[k] + w.b2lo, o1 = res1[k] + w.b2hi;  // the residual stream: exact f32, in this lane's registers
-        o0 = product3(w.ph[0], w.pl[0], nh[k], nl[k], o0);
-        o1 = product3(w.ph[1], w.pl[1], nh[k], nl[k], o1);
+        f32x4 o0 = res0[k] + b2lo, o1 = res1[k] + b2hi;  // the residual stream: exact f32, in this lane's registers
+        o0 = product3(p0h, p0l, nh[k], nl[k], o0);
+        o1 = product3(p1h, p1l, nh[k], nl[k], o1);
         res0[k] = o0, res1[k] = o1;
         bf16x8 oh, ol;
         split8(o0, o1, oh, ol);
-        *reinterpret_cast<bf16x8 *>(yh + (unsigned)R[k] * kRS + 8 * q) = oh;
-        *reinterpret_cast<bf16x8 *>(yl + (unsigned)R[k] * kRS + 8 * q) = ol;
+        *reinterpret_cast<bf16x8 *>(yh + wo[k]) = oh;
+        *reinterpret_cast<bf16x8 *>(yl + wo[k]) = ol;
     }
 }
 
@@ -589,19 +617,21 @@ __device__ __forceinline__ void tiles_split(const SplitW &w, int d, int T, int Z
 // with up to four tiles each.
 template <int MAXT>
 struct TilesS {
-    int n, R[MAXT], Rc[MAXT], t[MAXT], g[MAXT];
+    int n, R[MAXT], t[MAXT], g[MAXT];
+    unsigned ro[MAXT], wo[MAXT];  // element offsets of this lane's row pieces in an image: row Rc (reads), row R (its own output)
     f32x4 r0[MAXT], r1[MAXT];  // the residual stream of this lane's rows: channels 4q + r and 16 + 4q + r
 };
 template <int kMaxTilesS, bool TRAIN>
-__device__ __forceinline__ void run_block_split(const SplitW &w, int d, int T, int ZR, TilesS<kMaxTilesS> &ti, int q,
+__device__ __forceinline__ void run_block_split(const bf16x8 *w, int lane, int d, int T, int ZR, TilesS<kMaxTilesS> &ti, int q,
                                                 const __bf16 *__restrict__ xh, const __bf16 *__restrict__ xl, __bf16 *__restrict__ yh,
                                                 __bf16 *__restrict__ yl, const TrainBlk &tb) {
+    const unsigned zo = (unsigned)ZR * kRS + 8 * q;
 #pragma unroll
     for (int i = 0; i < kMaxTilesS; i += 2) {
         if (i + 1 < ti.n)
-            tiles_split<2, TRAIN>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
+            tiles_split<2, TRAIN>(w, lane, d, T, zo, ti.R + i, ti.ro + i, ti.wo + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
         else if (i < ti.n)
-            tiles_split<1, TRAIN>(w, d, T, ZR, ti.R + i, ti.Rc + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
+            tiles_split<1, TRAIN>(w, lane, d, T, zo, ti.R + i, ti.ro + i, ti.wo + i, ti.t + i, ti.g + i, q, xh, xl, yh, yl, ti.r0 + i, ti.r1 + i, tb);
     }
 }
 
@@ -648,7 +678,8 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
     for (int i = 0; i < kMaxTilesS; ++i) {
         const int u = wave + i * nw;
         const int R = 16 * u + j, Rc = min(R, GR - 1);
-        ti.R[i] = R, ti.Rc[i] = Rc, ti.g[i] = Rc / T, ti.t[i] = Rc - ti.g[i] * T;
+        ti.R[i] = R, ti.g[i] = Rc / T, ti.t[i] = Rc - ti.g[i] * T;
+        ti.ro[i] = (unsigned)Rc * kRS + 8 * q, ti.wo[i] = (unsigned)R * kRS + 8 * q;
         if (u < units) ti.n = i + 1;
     }
     const int nslot = a.n_blocks + 1;
@@ -699,7 +730,7 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
         for (int it = 0; it < kMaxTilesS; ++it) {
             ti.r0[it] = bl, ti.r1[it] = bh;
             if (it >= ti.n) continue;
-            const float *xr = X + ((size_t)n0 * T + ti.Rc[it]) * a.F + 8 * q;
+            const float *xr = X + ((size_t)n0 * T + ti.g[it] * T + ti.t[it]) * a.F + 8 * q;
             f32x4 xv[16];
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {  // all loads of the tile first (8 steps x 2 float4)
@@ -734,8 +765,8 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
         if (i >= ti.n) break;
         bf16x8 oh, ol;
         split8(ti.r0[i], ti.r1[i], oh, ol);
-        *reinterpret_cast<bf16x8 *>(h0 + (unsigned)ti.R[i] * kRS + 8 * q) = oh;
-        *reinterpret_cast<bf16x8 *>(l0 + (unsigned)ti.R[i] * kRS + 8 * q) = ol;
+        *reinterpret_cast<bf16x8 *>(h0 + ti.wo[i]) = oh;
+        *reinterpret_cast<bf16x8 *>(l0 + ti.wo[i]) = ol;
     }
 
     // the all-zero row of every image (what out-of-range taps read): written HERE, behind the layer-0 phase, whose operand staging
@@ -747,12 +778,11 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
     // ---- the residual blocks ----------------------------------------------------------------------------------------------------
     __bf16 *xh = h0, *xl = l0, *yh = h1, *yl = l1;
     {
-        SplitW w;
         for (int blk = 0; blk < a.n_blocks; ++blk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of block blk's operands have landed ...
             __syncthreads();                                  // ... everybody's have, and block blk - 1 is complete in the images
-            if (blk + 1 < a.n_blocks) stage(blk + 1);
-            load_split_w(w, wslot + (size_t)(blk & 1) * 2 * kSlotOps, lane, q);
+            if (blk + 1 < a.n_blocks && !(a.tune & 2)) stage(blk + 1);
+            const bf16x8 *w = wslot + (size_t)(blk & 1) * 2 * kSlotOps;
             TrainBlk tb{nullptr, nullptr, 0, 0, GR};
             if constexpr (TRAIN) {
                 save_acts(blk);
@@ -760,7 +790,7 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
                 tb.upre = tio.upre ? tio.upre + (size_t)n0 * tb.ustride + (size_t)blk * T * C : nullptr;
                 tb.drop = tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * tb.dstride + (size_t)blk * C : nullptr;
             }
-            run_block_split<kMaxTilesS, TRAIN>(w, 1 << (blk % a.n_dil), T, ZR, ti, q, xh, xl, yh, yl, tb);
+            if (!(a.tune & 1)) run_block_split<kMaxTilesS, TRAIN>(w, lane, 1 << (blk % a.n_dil), T, ZR, ti, q, xh, xl, yh, yl, tb);
             __bf16 *th = xh, *tl = xl;
             xh = yh, xl = yl, yh = th, yl = tl;
         }
@@ -776,8 +806,8 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
         for (int r = 0; r < 4; ++r) v0[r] = fmaxf(v0[r], 0.f), v1[r] = fmaxf(v1[r], 0.f);
         bf16x8 oh, ol;
         split8(v0, v1, oh, ol);
-        *reinterpret_cast<bf16x8 *>(xh + (unsigned)ti.R[i] * kRS + 8 * q) = oh;
-        *reinterpret_cast<bf16x8 *>(xl + (unsigned)ti.R[i] * kRS + 8 * q) = ol;
+        *reinterpret_cast<bf16x8 *>(xh + ti.wo[i]) = oh;
+        *reinterpret_cast<bf16x8 *>(xl + ti.wo[i]) = ol;
     }
     __syncthreads();
 
@@ -903,11 +933,13 @@ static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int
     fill_args(m, N, &a, &lds);
     a.from_x0 = from_x0;
     if (const char *ev = smh::probe_env("SMH_TCN_BLOCKS")) a.n_blocks = atoi(ev);  // timing probe (outputs invalid): fewer residual blocks
+    if (const char *ev = smh::probe_env("SMH_TCN_TUNE")) a.tune = atoi(ev);  // timing probes: 1 = no tile work, 2 = no operand staging
     SMH_REQUIRE(lds <= 156 * 1024, "patch_size %d too long for the LDS-resident TCN", a.T);
     if (split) {
         const int units_s = (std::min(a.G, N) * a.T + 15) / 16;
         const bool two = units_s <= 24;  // at most two column tiles per wave on up to 12 waves
-        const int nwaves_s = two ? std::min(12, std::max(8, (units_s + 1) / 2)) : 8;
+        int nwaves_s = two ? std::min(12, std::max(8, (units_s + 1) / 2)) : 8;
+        if (const char *ev = getenv("SMH_BF16_NW")) nwaves_s = two ? std::min(12, std::max((units_s + 1) / 2, atoi(ev))) : 8;  // tuning
         // residual image + four split images (hi / lo of two buffers, a zero row each)
         SMH_REQUIRE(a.n_mt <= 5, "smh_model_forward_bf16: more than five M-tiles of Dense-on-trunk outputs");
         const size_t lds_s = 4 * (size_t)(a.GRP + 1) * kRS * sizeof(__bf16) + 2 * 2 * kSlotOps * 16 + sizeof(float) * (size_t)nwaves_s * a.G * kPS;

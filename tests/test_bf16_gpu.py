@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # measured on seeded random weights with perturbed BatchNorm statistics (the hardest case for rounding: 24 blocks of
 # 'divide by the channel maximum'): max |output difference| 2-4e-2, argmax of the 3C head identical on > 99.5 %
-TOL_SPLIT = 1e-4        # "bf16" = split operands (measured 4.7-7.4e-5 in round 4; SURVEY 8(d') would allow 2e-2)
+TOL_SPLIT = 1e-4        # "bf16" = split operands (measured 4.9-9.0e-5 in round 4; SURVEY 8(d') would allow 2e-2)
 SINGLE_BF16_BAND = (2e-2, 8e-2)   # one bf16 per operand: measured 3.5-5e-2, i.e. OUTSIDE SURVEY 8(d')'s 2e-2
 MIN_AGREE = 0.995
 
