@@ -150,14 +150,16 @@ int smh_frontend_f32(const smh_ctx *ctx, const float *d_audio, int B, int n_samp
 
 /* ---- ragged batches: B clips of DIFFERENT lengths in one call (the reference's generators take whole files of any length
  * one at a time: Proposed_Work_Results.py:92-95, 131-134, 189-192, 465-474).  d_audio holds the clips at sample offsets
- * h_offsets[b] with h_lengths[b] samples each (HOST arrays; keep every offset a multiple of 2 samples = 8 bytes so that each
- * clip takes the same kernels as in smh_frontend_f32 and gets the same bits).  Consecutive clips of equal length lying back
- * to back are batched into one launch set.  Outputs are concatenated: clip b's featuregram (2*rows, T_b) starts at float
+ * h_offsets[b] with h_lengths[b] samples each (HOST arrays; keep every offset a multiple of 4 samples = 16 bytes: a clip that
+ * starts off an 8-byte boundary is processed alone, through smh_frontend_f32).  ONE LAUNCH PER STAGE for all clips: the lengths
+ * become a descriptor table + (clip, tile) work lists, uploaded in one copy from a pinned slot of the context, and the STFT, the
+ * medians and the feature kernels each run once over every clip (smh_ragged.hip); a clip gets bit for bit what smh_frontend_f32
+ * gives it alone or in an equal-length batch.  Outputs are concatenated: clip b's featuregram (2*rows, T_b) starts at float
  * h_fv_off[b] of d_fv, its nP_b standardised time-major patches at patch h_patch_off[b] of d_patches ((W, 2*rows) each).
- * smh_frontend_ragged_sizes fills the per-clip tables (each may be NULL) and the workspace requirement; W <= 0: no patches.
- * The clips' dependent kernel chains are spread over up to four streams of the library's own, forked from `stream` at entry and joined
- * back into it at exit (the call is stream-ordered for the caller like every other entry point); the workspace requirement is one
- * slice per such lane, a smaller workspace gives fewer lanes (at least one slice: the largest launch set's smh_frontend_workspace_bytes). */
+ * smh_frontend_ragged_sizes fills the per-clip tables (each may be NULL) and the workspace requirement (tables + S / harm / perc of
+ * every clip, at most 8 GiB: beyond that, or with a smaller workspace than asked for, the call runs in sub-batches; never less than
+ * the largest single clip needs); W <= 0: no patches.  d_work must start on a 16-byte boundary.  Stream-ordered on `stream`; not
+ * capturable in a hipGraph (the table upload reads a staging buffer that the next call rewrites). */
 int smh_frontend_ragged_sizes(const smh_ctx *ctx, const long long *h_offsets, const int *h_lengths, int B, int W, int shift,
                               long long *h_fv_off /* B+1 */, long long *h_patch_off /* B+1 */, int *h_T /* B */,
                               int *h_nP /* B */, size_t *work_bytes);

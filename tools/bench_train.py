@@ -140,7 +140,8 @@ def main():
         print(json.dumps({
             "metric": "clips/sec HPSS + B3_MTL training step (1s@16kHz)", "value": round(world * B * args.steps / dt, 1),
             "unit": "clips/s", "n_gpus": world, "ranks_reporting": ran, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "dtype": "f32",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "dtype": "f32" if args.dtype == "f32" else "f32 master weights, saved activations, backward and optimiser; forward on split bf16 operands (3 bf16 MFMA per f32 product)",
             "data": "synthetic", "front_end_overlapped_with_previous_step": not serial,
             "deterministic_gradients": bool(args.deterministic),
             "config": {"workload": "%d clips per GPU per step: front end 21x11 -> W=%d patches (%d per clip) -> B3_MTL(%d-class) "
