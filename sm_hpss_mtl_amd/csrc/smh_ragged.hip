@@ -599,7 +599,8 @@ void classify(const smh_ctx *ctx, const float *d_audio, const long long *off, co
     for (int b = 0; b < B; ++b) {
         if (!rag_clip_ok(ctx, p.T[b])) continue;
         if (need8 && ((reinterpret_cast<uintptr_t>(d_audio) + (uintptr_t)off[b] * 4) % 8) != 0) continue;
-        if (smh_features_blocked_ok(ctx, p.T[b], 0)) cls[b] = (p.T[b] & 1) ? 1 : 0;
+        // (even T: one workgroup per clip half; odd T -- or SMH_FEAT_NOPAIR, which makes smh_frontend_f32 choose the same -- one per clip)
+        if (smh_features_blocked_ok(ctx, p.T[b], 0)) cls[b] = ((p.T[b] & 1) || getenv("SMH_FEAT_NOPAIR")) ? 1 : 0;
         else cls[b] = 2;
     }
 }

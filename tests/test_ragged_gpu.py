@@ -90,6 +90,9 @@ def test_ragged_sub_batches_and_stream_order(fe):
     stream right behind the call are complete; a workspace below one clip's need is refused; featuregrams without patches."""
     from sm_hpss_mtl_amd import _lib
     from sm_hpss_mtl_amd.synth import synth_clips
+    forced = [n for n in ("SMH_FEAT_TWO_KERNELS", "SMH_MEDIAN_NOSPLIT", "SMH_RAGGED_PERFILE", "SMH_FEAT_TAPS") if os.environ.get(n)]
+    if forced:  # these switches send every clip through smh_frontend_f32 alone: no tables, no sub-batches to test
+        pytest.skip("ragged kernels switched off by " + ", ".join(forced))
     rng = np.random.default_rng(2)
     lens = [int(rng.integers(6000, 70000)) // 2 * 2 for _ in range(23)] + [16000, 16000]
     clips = [synth_clips(1, seed=300 + i, n_samples=n)[0] for i, n in enumerate(lens)]
