@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # compare-and-swap loop per atomic instead of global_atomic_add_f32 (the backward kernel was 8.6 ms because of it).
 # smh_tcn: relu / channel maximum of accumulator values; same canonicalisation issue (16 extra v_max per 16-frame tile).
 EXTRA_FLAGS = {"smh_median_split.hip": ["-fno-honor-nans"], "smh_train.hip": ["-munsafe-fp-atomics"],
-               "smh_tcn.hip": ["-fno-honor-nans"], "smh_tcn_bf16.hip": ["-fno-honor-nans"]}
+               "smh_tcn.hip": ["-fno-honor-nans"], "smh_tcn_bf16.hip": ["-fno-honor-nans"],
+               "smh_train_bf16.hip": ["-munsafe-fp-atomics", "-fno-honor-nans"]}
 
 
 def _sources():

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "smh_model.h"
+#include "smh_train_bwd.h"
 
 using namespace smh_tcn;
 
@@ -363,18 +364,6 @@ heads_train_kernel(HeadsArgs a, const float *__restrict__ pre, const float *__re
                tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
 }
 
-// Weight-gradient accumulation.  Default: hardware float atomics (global_atomic_add_f32, -munsafe-fp-atomics) -- fastest, but the
-// order in which the workgroups' contributions meet is not fixed, so a gradient's last bits differ from run to run.
-// DETERMINISTIC mode (smh_trainer_set_deterministic): every contribution is rounded to a 2^-36 grid and added to a 64-bit
-// integer accumulator with an integer atomic.  Integer addition is associative, so the sum does not depend on arrival order:
-// two runs of the same step give the same bits.  Range +-2^27 per tensor element, resolution 1.5e-11 (a float32 sum of these
-// gradients resolves ~1e-8 at best); det_finalize_kernel converts the accumulators back into the float gradient and clears them.
-constexpr float kDetScale = 68719476736.0f;          // 2^36
-constexpr double kDetInvScale = 1.0 / 68719476736.0;
-__device__ __forceinline__ void gadd(float *grad, unsigned long long *gq, size_t i, float v) {
-    if (gq) atomicAdd(gq + i, (unsigned long long)__float2ll_rn(v * kDetScale));  // (uniform branch)
-    else atomicAdd(grad + i, v);
-}
 __global__ void det_finalize_kernel(unsigned long long *__restrict__ gq, float *__restrict__ grad, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -385,15 +374,6 @@ __global__ void det_finalize_kernel(unsigned long long *__restrict__ gq, float *
         }
     }
 }
-
-struct BwdArgs {
-    unsigned long long *gq;  // deterministic mode: the fixed-point accumulators (n_params), else nullptr
-    int N, T, F, n_blocks, n_dil, D, NH, n_classes, n_heads;
-    int stamps;  // tools only (SMH_BWD_STAMPS): workgroup 0 prints the time its phases took, summed over the blocks
-    int split3;  // MFMA kernel: a lone last-round tile of phase 3 is shared by two waves (SMH_BWD_SPLIT=0 switches it off: A/B and tests)
-    int use_wt;  // VALU kernel: keep transposed LDS copies of the block kernels (0 for patches so long that they do not fit)
-    Offsets off;
-};
 
 // One workgroup = kBG patches.  All buffers are (rows = g*T + t, channel) with stride kBS.
 __global__ void __launch_bounds__(kBThreads)
@@ -1263,6 +1243,8 @@ struct smh_trainer {
     unsigned long long *d_gq = nullptr;       // deterministic mode: fixed-point gradient accumulators (n_params), else nullptr
     float *d_sumsq = nullptr, *d_scratch_out = nullptr;
     float *d_upre = nullptr;  // (max_batch, n_blocks, T, 32): TrainIO::upre
+    void *d_bwd_pack = nullptr;  // the blocks' kernels as split bf16 A operands of the backward pass (smh_train_bf16.hip), dtype 1 only
+    size_t bwd_pack_cap = 0;
     double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
     Segment *d_segs = nullptr;
     int dtype = 0;             // smh_trainer_set_dtype: 0 = exact-f32 matrix products, 1 = split-bf16 operands (f32 accumulators, f32 master weights)
@@ -1345,6 +1327,7 @@ extern "C" void smh_trainer_destroy(smh_trainer *t) {
     (void)hipFree(t->d_segs);
     (void)hipFree(t->d_l2part);
     (void)hipFree(t->d_gq);
+    (void)hipFree(t->d_bwd_pack);
     delete t;
 }
 
@@ -1428,9 +1411,19 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 4 * C * kWS + kMG * kPS + C + kZW);
     const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS + C + kZW);  // kernels stay in global memory
     const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
-    if ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU")) {
+    // dtype 1: the residual blocks' backward on the bf16 matrix pipe (smh_train_bf16.hip); patch geometries outside its LDS plan, and
+    // SMH_BWD_BF16=0 (A/B and tests), keep the exact-f32 kernel behind the bf16 forward
+    bool bwd_done = false;
+    if (t->dtype == 1 && !getenv("SMH_TRAIN_VALU") && !(getenv("SMH_BWD_BF16") && atoi(getenv("SMH_BWD_BF16")) == 0)) {
+        rc = launch_backward_bf16(ba, &t->d_bwd_pack, &t->bwd_pack_cap, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,
+                                  (const float *)t->d_upre, st);
+        if (rc == SMH_OK) bwd_done = true;
+        else if (rc != kBwdBf16Unsupported) return rc;
+    }
+    if (bwd_done || ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU"))) {
         const dim3 grid((N + kMG - 1) / kMG);
-        if (short_ok) {
+        if (bwd_done) {
+        } else if (short_ok) {
             auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
             hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,

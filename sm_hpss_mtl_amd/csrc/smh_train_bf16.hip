@@ -1,0 +1,522 @@
+// B3_MTL backward pass of the residual blocks on the bf16 matrix pipe -- the trainer's dtype 1 (smh_trainer_set_dtype): every matrix
+// product takes SPLIT operands (x = hi + lo, both bf16; hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, f32 accumulators), so the
+// products are f32-grade (~1e-5 relative) at a fifth of the exact-f32 pipe's time (three 16-cycle instructions for k = 32 against
+// eight 32-cycle ones).  Same inputs and outputs as tcn_backward_mfma_kernel (smh_train.hip): the activations and the dilated-conv
+// outputs the training forward saved (TrainIO::acts / upre), the SpatialDropout1D masks, d loss / d pre of the Dense-on-trunk
+// outputs; the weight gradients are added to `grad` (float atomics, or the deterministic fixed-point accumulators).
+// Mirrors the reference's model.fit backward of lib/proposed_architectures.py:127-154 (keras-tcn residual blocks); arithmetic
+// restated in oracle/b3_mtl_train.py.
+//
+// Layouts.  "C layout": a lane (q = lane / 16, j = lane % 16) of a tile's wave holds, for frame 16 u + j, the channels 4 q + r and
+// 16 + 4 q + r (the MFMA accumulator layout with channels as M) -- as eight values in the order k' = 8 q + e they are at once the
+// B operand of a product over channels and the A operand of a product that TRANSPOSES them: D[frame][channel] = sum_k' v[frame][k']
+// sel[k'][channel] with a 0 / 1 selection matrix is exact for bf16 values and leaves lane (q, j) with frames 16 u + 4 q + r of
+// channel j ("T layout"): four consecutive frames, one ds_write_b64 into a frame-contiguous image.  The weight gradients are
+// products over FRAMES (dW[c][co] = sum_t a[t][c] b[t][co]), whose operands must hold eight consecutive frames per lane: they read
+// those images.
+//
+// One workgroup = G patches (2 at the reference's W = 68: 2 x 65 KB of images + one 16 KB operand slot), 8 waves per patch; per block
+//   A  (tile waves) x, y = norm(relu(u)), g, du -> frame-contiguous images xT, yT, gT, duT (hi and lo) and du rows (hi, lo);
+//      dyn = W2 . g (6 products) and the relu / channel-max backward in registers;
+//   -- barrier --
+//   B  (all waves) the 16 weight-gradient tiles dW2 (2 x 2), dW1[tap] (3 x 2 x 2), one per wave over the workgroup's patches, K =
+//      frames (three steps of 32 at W = 68); a side tap reads xT at frame t + off: whole 8-frame chunks when the dilation is a multiple
+//      of 8 (a chunk outside the patch is zero, no halo needed), otherwise five dwords and a funnel shift inside an 8-frame halo.  The bias gradients are two more products with an all-ones A operand.
+//   C  (tile waves) g += sum_tap W1[tap] . du[t - off] (18 products), g stays in the lane's registers over the whole kernel;
+//   -- barrier --
+// The block's kernels come as split A operands from a packed copy (pack_bwd_kernel, once per step) by LDS-DMA into ONE slot: the
+// 1x1 kernel (used in A) is replaced behind the first barrier, the dilated kernel (used in C) behind the second.
+#include <algorithm>
+#include <cstdlib>
+
+#include "smh_train_bwd.h"
+
+using namespace smh_tcn;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// two f32 -> packed hi = bf16(x), lo = bf16(x - hi) (smh_tcn_bf16.hip: split2)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const bf16x2s h = __builtin_convertvector(f32x2s{x0, x1}, bf16x2s);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2s hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const bf16x2s l = __builtin_convertvector(f32x2s{x0, x1} - hf, bf16x2s);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, bf16x8 &hi, bf16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(a[0], a[1], h0, l0);
+    split2(a[2], a[3], h1, l1);
+    split2(b[0], b[1], h2, l2);
+    split2(b[2], b[3], h3, l3);
+    hi = __builtin_bit_cast(bf16x8, u32x4s{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(bf16x8, u32x4s{l0, l1, l2, l3});
+}
+__device__ __forceinline__ f32x4 product3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+    c = mfma_bf16(al, bh, c);  // small terms first
+    c = mfma_bf16(ah, bl, c);
+    return mfma_bf16(ah, bh, c);
+}
+// combine over the four lanes that hold the same frame (l, l ^ 16, l ^ 32, l ^ 48)
+template <class F>
+__device__ __forceinline__ float quad_reduce(float v, F f) {
+    const unsigned u = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = f(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    const unsigned ua = __float_as_uint(a);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return f(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+}
+
+constexpr int kDuRow = 80;       // bytes per row of the du images: 32 bf16 + 16 bytes of padding (smh_tcn_bf16.hip: kRS)
+constexpr int kSlotHalf = 8192;  // bytes of hi operands in the slot (8 units x 64 lanes x 16 bytes), then the lo operands
+constexpr int kUnitsPerBlk = 8;  // operand units per block: W2 [mt] (2), W1 [tap][mt] (6)
+
+// LDS plan (host: bwd_geo)
+struct BwdGeo {
+    int G;        // patches per workgroup
+    int units;    // 16-frame tiles per patch (<= 8: one per wave)
+    int K32;      // k steps of 32 frames in the weight-gradient products
+    int halo;     // zero frames in front of / behind the xT rows: 8 -- only dilations below 8 read across a chunk boundary
+    int sxt, st;  // row strides in bytes of xT and of yT / gT / duT (16 x odd)
+    int o_x, o_y, o_g, o_du_t, o_du;  // byte offsets of the image pairs inside a patch's region (hi, then lo at + the pair's half)
+    int h_x, h_t, h_du;               // the halves: 32 * sxt, 32 * st, (T + 1) * kDuRow
+    int per_patch;                    // bytes per patch
+};
+
+// wave -> weight-gradient tile job (phase B), a permutation of 0..15: job < 4: dW2 (mt = job / 2, nt = job % 2); else tap = (job - 4) / 4,
+// mt, nt.  The side-tap jobs (4..7, 12..15: funnel-shifted operand reads) go to the waves that own no 16-frame tile at W = 68
+// (5, 6, 7 of patch 0; 8, 14, 15 of patch 1) and to the two lone fifth tiles
+// (nibble w of the constant: a table in memory was a global load, and the vmcnt(0) behind it waited for the block's prefetch from HBM)
+constexpr unsigned long long kJobOfWave = 0xDCFBA987654E3210ull;  // waves 0..15: 0, 1, 2, 3, 14, 4, 5, 6, 7, 8, 9, 10, 11, 15, 12, 13
+
+// canonical f32 kernels -> split A operands, one thread per 16-byte unit: dst[blk][hi 512 | lo 512] with unit e = mt (W2: dyn[c] = sum_co
+// k2[c][co] g[co]) or 2 + 2 tap + mt (W1: dx[c] += sum_co k1[tap][c][co] du[t - off][co]); lane (i, kg) holds row c = 16 mt + i, columns
+// co in the accumulator's channel order k' = 8 kg + e'
+__global__ void pack_bwd_kernel(const float *__restrict__ flat, Offsets off, int n_blocks, bf16x8 *__restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_blocks * kUnitsPerBlk * 64) return;
+    const int blk = idx / (kUnitsPerBlk * 64), e = (idx >> 6) % kUnitsPerBlk, lane = idx & 63, i = lane & 15, kg = lane >> 4;
+    const size_t wo = off.blk0 + (size_t)blk * off.blk_stride;
+    const float *src;
+    if (e < 2) src = flat + wo + 3 * C * C + C + (size_t)(16 * e + i) * C;
+    else src = flat + wo + ((size_t)((e - 2) >> 1) * C + 16 * ((e - 2) & 1) + i) * C;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src + 4 * kg), b = *reinterpret_cast<const f32x4 *>(src + 16 + 4 * kg);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? a[k] : b[k - 4];
+        hi[k] = (__bf16)v, lo[k] = (__bf16)(v - (float)hi[k]);
+    }
+    dst[(size_t)blk * 2 * kUnitsPerBlk * 64 + e * 64 + lane] = hi;
+    dst[(size_t)blk * 2 * kUnitsPerBlk * 64 + kUnitsPerBlk * 64 + e * 64 + lane] = lo;
+}
+
+__global__ void __launch_bounds__(1024)
+tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, const float *__restrict__ flatw,
+                         const bf16x8 *__restrict__ pk, const float *__restrict__ acts, const float *__restrict__ drop,
+                         const float *__restrict__ dpre, float *__restrict__ grad, const float *__restrict__ upre) {
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    const int T = a.T, nslot = a.n_blocks + 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    const int n0 = blockIdx.x * geo.G;
+    const int g_here = min(geo.G, a.N - n0);
+    // this wave's patch and 16-frame tile (patch 1's tiles sit one wave further on, so that the 5 + 5 tiles of two 68-frame patches
+    // spread 3 / 3 / 2 / 2 over the four SIMDs)
+    const int p = wave >> 3;
+    const int u = ((wave & 7) - p) & 7;
+    const bool has_tile = u < geo.units && p < g_here;
+    const int t = 16 * u + j;
+    const bool live = has_tile && t < T;
+    char *img = smb + (size_t)p * geo.per_patch;
+    char *wslot = smb + (size_t)geo.G * geo.per_patch;
+
+    // tools only (SMH_BWD_STAMPS): waves 0 (owns a tile) and 5 (owns none at W = 68) of workgroup 0 print their phases, summed over the blocks
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool stamping = a.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5);
+    if (stamping) tlast = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t_entry = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    auto lap = [&](int i) {
+        if (stamping) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            tph[i] += now - tlast;
+            tlast = now;
+        }
+    };
+    for (int i = tid; i < geo.G * geo.per_patch / 16; i += nt) reinterpret_cast<u32x4s *>(smb)[i] = u32x4s{0u, 0u, 0u, 0u};
+    // the block's operands: 16 pieces of 1 KiB (64 lanes x 16 bytes): hi W2 (0, 1), hi W1 (2..7), lo W2 (8, 9), lo W1 (10..15)
+    auto stage_piece = [&](int blk, int piece) {
+        const char *src = reinterpret_cast<const char *>(pk + (size_t)blk * 2 * kUnitsPerBlk * 64 + piece * 64 + lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(wslot + piece * 1024), 16, 0, 0);
+    };
+    auto stage_w2 = [&](int blk) {
+        for (int i = wave; i < 4; i += nw) stage_piece(blk, i < 2 ? i : 6 + i);
+    };
+    auto stage_w1 = [&](int blk) {
+        for (int i = wave; i < 12; i += nw) stage_piece(blk, i < 6 ? 2 + i : 4 + i);
+    };
+    if (a.n_blocks > 0) stage_w2(a.n_blocks - 1), stage_w1(a.n_blocks - 1);
+
+    // the selection operands of the transposing products: channel 16 h + n of the k' order sits at k' = 8 (n / 4) + 4 h + n % 4
+    bf16x8 sel[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sel[h][e] = (__bf16)((q == (j >> 2) && e == 4 * h + (j & 3)) ? 1.0f : 0.0f);
+
+    // ---- Dense-on-trunk backward: g = relu'(x_last) * (dpre @ Wh^T), in C layout, straight into the registers it lives in ----
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *xp = acts + (((size_t)(n0 + p) * nslot + a.n_blocks) * T + t) * C + 4 * q;
+        const f32x4 xl0 = *reinterpret_cast<const f32x4 *>(xp), xl1 = *reinterpret_cast<const f32x4 *>(xp + 16);
+        const float *dp = dpre + (size_t)(n0 + p) * kPS;  // (wave-uniform)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4);
+            const size_t k = (size_t)t * C + c;
+            float acc = 0.f;
+            for (int o = 0; o < a.n_classes; ++o) acc = fmaf(dp[o], flatw[a.off.c3_k + k * a.n_classes + o], acc);
+            for (int h = 0; h < a.n_heads; ++h) {
+                const float *wr = flatw + a.off.head[h] + k * kHidden;
+#pragma unroll
+                for (int v4 = 0; v4 < kHidden / 4; ++v4) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wr + 4 * v4);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc = fmaf(dp[a.n_classes + h * kHidden + 4 * v4 + jj], w[jj], acc);
+                }
+            }
+            const float xv = e < 4 ? xl0[e] : xl1[e - 4];
+            const float gv = xv > 0.f ? acc : 0.f;
+            if (e < 4) g0[e] = gv;
+            else g1[e - 4] = gv;
+        }
+    }
+
+    // register prefetch of a block's inputs for this lane's row: block input, saved dilated-conv output, dropout mask
+    f32x4 pf_x0, pf_x1, pf_u0, pf_u1, pf_d0, pf_d1;
+    auto prefetch = [&](int blk) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+        pf_x0 = pf_x1 = pf_u0 = pf_u1 = z;
+        pf_d0 = pf_d1 = one;
+        if (live) {
+            const float *xp = acts + (((size_t)(n0 + p) * nslot + blk) * T + t) * C + 4 * q;
+            pf_x0 = *reinterpret_cast<const f32x4 *>(xp), pf_x1 = *reinterpret_cast<const f32x4 *>(xp + 16);
+            const float *up = upre + (((size_t)(n0 + p) * a.n_blocks + blk) * T + t) * C + 4 * q;
+            pf_u0 = *reinterpret_cast<const f32x4 *>(up), pf_u1 = *reinterpret_cast<const f32x4 *>(up + 16);
+            if (drop) {
+                const float *dq = drop + ((size_t)(n0 + p) * a.n_blocks + blk) * C + 4 * q;
+                pf_d0 = *reinterpret_cast<const f32x4 *>(dq), pf_d1 = *reinterpret_cast<const f32x4 *>(dq + 16);
+            }
+        }
+    };
+    if (a.n_blocks > 0) prefetch(a.n_blocks - 1);
+
+    // frame-contiguous images of eight values in C layout: two exact transposing products per half (hi, lo), packed back to bf16
+    // (the upper halves of the f32 results), one 8-byte write each; e0 = element index of the tile's first frame in the row
+    auto transpose_store = [&](bf16x8 vh, bf16x8 vl, char *ih, char *il, int stride, int e0) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 th = mfma_bf16(vh, sel[h], z), tl = mfma_bf16(vl, sel[h], z);
+            u32x2s wh, wl;
+            wh[0] = __builtin_amdgcn_perm(__float_as_uint(th[1]), __float_as_uint(th[0]), 0x07060302u);
+            wh[1] = __builtin_amdgcn_perm(__float_as_uint(th[3]), __float_as_uint(th[2]), 0x07060302u);
+            wl[0] = __builtin_amdgcn_perm(__float_as_uint(tl[1]), __float_as_uint(tl[0]), 0x07060302u);
+            wl[1] = __builtin_amdgcn_perm(__float_as_uint(tl[3]), __float_as_uint(tl[2]), 0x07060302u);
+            const int o = (16 * h + j) * stride + 2 * (e0 + 4 * q);
+            *reinterpret_cast<u32x2s *>(__builtin_assume_aligned(ih + o, 8)) = wh;
+            *reinterpret_cast<u32x2s *>(__builtin_assume_aligned(il + o, 8)) = wl;
+        }
+    };
+    auto ld16 = [&](const char *ptr) { return *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(ptr, 16)); };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // images zeroed, the last block's operands in the slot
+    lap(0);
+
+    for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
+        const int d = 1 << (blk % a.n_dil);
+        const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
+        const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
+        if (blk < a.n_blocks - 1) stage_w1(blk);  // (phase C of the block before is behind the barrier)
+        // ---- phase A ---------------------------------------------------------------------------------------------------------------
+        if (has_tile) {  // (wave-uniform)
+            const f32x4 u0 = pf_u0, u1 = pf_u1, dm0 = pf_d0, dm1 = pf_d1;
+            bf16x8 vh, vl;
+            split8(pf_x0, pf_x1, vh, vl);
+            transpose_store(vh, vl, img + geo.o_x, img + geo.o_x + geo.h_x, geo.sxt, geo.halo + 16 * u);
+            float r0[4], r1[4], mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                r0[r] = fmaxf(u0[r], 0.f), r1[r] = fmaxf(u1[r], 0.f);
+                mx = fmaxf(mx, fmaxf(r0[r], r1[r]));
+            }
+            mx = quad_reduce(mx, [](float x, float y) { return fmaxf(x, y); });
+            const float inv_m = __builtin_amdgcn_rcpf(mx + kNormEps);  // the forward's own 1 / (max + eps)
+            f32x4 y0, y1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y0[r] = live ? r0[r] * inv_m * dm0[r] : 0.f;
+                y1[r] = live ? r1[r] * inv_m * dm1[r] : 0.f;
+            }
+            split8(y0, y1, vh, vl);
+            transpose_store(vh, vl, img + geo.o_y, img + geo.o_y + geo.h_t, geo.st, 16 * u);
+            bf16x8 gh, gl;
+            split8(g0, g1, gh, gl);
+            transpose_store(gh, gl, img + geo.o_g, img + geo.o_g + geo.h_t, geo.st, 16 * u);
+            // dyn[c][frame] = sum_co W2[c][co] g[frame][co]
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            d0 = product3(ld16(wslot + (0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (0 * 64 + lane) * 16), gh, gl, d0);
+            d1 = product3(ld16(wslot + (1 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (1 * 64 + lane) * 16), gh, gl, d1);
+            float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d0[r] *= dm0[r], d1[r] *= dm1[r];
+                s1 = fmaf(d0[r], r0[r], s1);
+                s1 = fmaf(d1[r], r1[r], s1);
+                cnt += (r0[r] == mx ? 1.f : 0.f) + (r1[r] == mx ? 1.f : 0.f);
+            }
+            s1 = quad_reduce(s1, [](float x, float y) { return x + y; });
+            cnt = quad_reduce(cnt, [](float x, float y) { return x + y; });
+            const float corr = s1 * inv_m * inv_m / cnt;
+            f32x4 du0, du1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a0 = d0[r] * inv_m, a1 = d1[r] * inv_m;
+                if (r0[r] == mx && r0[r] > 0.f) a0 -= corr;
+                if (r1[r] == mx && r1[r] > 0.f) a1 -= corr;
+                du0[r] = (live && u0[r] > 0.f) ? a0 : 0.f;
+                du1[r] = (live && u1[r] > 0.f) ? a1 : 0.f;
+            }
+            split8(du0, du1, vh, vl);
+            if (live) {
+                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + geo.o_du + t * kDuRow + 16 * q, 16)) = vh;
+                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + geo.o_du + geo.h_du + t * kDuRow + 16 * q, 16)) = vl;
+            }
+            transpose_store(vh, vl, img + geo.o_du_t, img + geo.o_du_t + geo.h_t, geo.st, 16 * u);
+        }
+        lap(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the dilated kernel have landed
+        __syncthreads();
+        lap(2);
+        if (blk > 0) {
+            stage_w2(blk - 1);  // phase A was the 1x1 kernel's last reader
+            prefetch(blk - 1);
+        }
+        // ---- phase B: weight gradients ---------------------------------------------------------------------------------------------
+        for (int slot = wave; slot < 16; slot += nw) {
+            const int job = (int)((kJobOfWave >> (4 * slot)) & 15ull);
+            int tap = 1, mt, nt_;
+            if (job < 4) mt = job >> 1, nt_ = job & 1;
+            else tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
+            const bool w2 = job < 4;
+            const int off = w2 ? 0 : (tap - 1) * d;
+            if (off != 0 && d >= T) continue;  // a side tap that only ever sees the zero padding
+            const bool bias = mt == 0 && tap == 1;
+            const int oA = w2 ? geo.o_y : geo.o_x, hA = w2 ? geo.h_t : geo.h_x, sA = w2 ? geo.st : geo.sxt;
+            const int oB = w2 ? geo.o_g : geo.o_du_t;
+            const int eA = (w2 ? 0 : geo.halo) + 8 * q + off;  // element index of this lane's first frame in its A row
+            const int arow = oA + (16 * mt + j) * sA;  // (its first 16 bytes: the zero halo chunk of an xT row)
+            const int aoff = arow + 2 * (eA & ~1), boff = oB + (16 * nt_ + j) * geo.st + 16 * q;
+            const unsigned sh = (eA & 1) ? 16u : 0u;
+            const bool aligned = (off & 7) == 0;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+            auto run = [&](auto aligned_c) {
+                constexpr bool AL = decltype(aligned_c)::value;
+                auto lda = [&](const char *ptr) {
+                    if constexpr (AL) {
+                        return ld16(ptr);
+                    } else {  // five dwords from a 4-byte aligned address, shifted down by 0 or 16 bits
+                        const unsigned *w = reinterpret_cast<const unsigned *>(__builtin_assume_aligned(ptr, 4));
+                        const unsigned w0 = w[0], w1 = w[1], w2_ = w[2], w3 = w[3], w4 = w[4];
+                        return __builtin_bit_cast(bf16x8, u32x4s{__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2_, w1, sh),
+                                                                 __builtin_amdgcn_alignbit(w3, w2_, sh), __builtin_amdgcn_alignbit(w4, w3, sh)});
+                    }
+                };
+                for (int pp = 0; pp < g_here; ++pp) {
+                    const char *ip = smb + (size_t)pp * geo.per_patch;
+                    for (int s = 0; s < geo.K32; ++s) {
+                        const char *pa = ip + aoff + 64 * s;
+                        if constexpr (AL) {
+                            // an aligned tap moves whole 8-frame chunks: one outside the patch's 32 K32 frames is zero (the halo chunk
+                            // at the start of the row), a step with all four chunks outside is skipped (d = 64 at W = 68: two of three)
+                            if (32 * s + off + 24 < 0 || 32 * s + off >= 32 * geo.K32) continue;  // (uniform)
+                            const bool ok = (unsigned)(32 * s + 8 * q + off) < (unsigned)(32 * geo.K32);
+                            pa = ok ? pa : ip + arow;
+                        }
+                        const bf16x8 ah = lda(pa), al = lda(pa + hA);
+                        const bf16x8 bh = ld16(ip + boff + 64 * s), bl = ld16(ip + boff + geo.h_t + 64 * s);
+                        acc = product3(ah, al, bh, bl, acc);
+                        if (bias) {  // (uniform) column sums of B: the bias gradient of this column tile
+                            accb = mfma_bf16(ones, bl, accb);
+                            accb = mfma_bf16(ones, bh, accb);
+                        }
+                    }
+                }
+            };
+            if (aligned) run(std::true_type{});
+            else run(std::false_type{});
+            const unsigned gbase = (unsigned)(w2 ? o_k2 : o_k1 + (size_t)tap * C * C), gbias = (unsigned)(w2 ? o_b2 : o_b1);
+            // the pieces of the next block's 1x1 kernel this wave requested at the top of the phase have landed by now; waiting here, IN
+            // FRONT of the atomics, keeps their round trips out of the wait (vmcnt counts them too) -- the barrier below needs no wait
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gadd(grad, a.gq, gbase + (unsigned)((16 * mt + 4 * q + r) * C + 16 * nt_ + j), acc[r]);
+            if (bias && q == 0) gadd(grad, a.gq, gbias + 16 * nt_ + j, accb[0]);
+        }
+        lap(3);
+        // ---- phase C: g[frame][c] += sum_tap sum_co W1[tap][c][co] du[frame - off][co] ------------------------------------------
+        if (has_tile) {
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int off = (tap - 1) * d;
+                const bool ok = (t - off >= 0) && (t - off < T);
+                if (tap != 1 && !__any(ok)) continue;
+                const int row = ok ? t - off : T;  // row T of the du images stays zero
+                const bf16x8 bh = ld16(img + geo.o_du + row * kDuRow + 16 * q), bl = ld16(img + geo.o_du + geo.h_du + row * kDuRow + 16 * q);
+                const int e0 = 2 + 2 * tap;
+                g0 = product3(ld16(wslot + (e0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (e0 * 64 + lane) * 16), bh, bl, g0);
+                g1 = product3(ld16(wslot + ((e0 + 1) * 64 + lane) * 16), ld16(wslot + kSlotHalf + ((e0 + 1) * 64 + lane) * 16), bh, bl, g1);
+            }
+            if (!live) g0 = g1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lap(4);
+        // (not __syncthreads(): its workgroup-scope fence is an s_waitcnt vmcnt(0), i.e. a wait for the round trips of the weight-gradient
+        // atomics this wave has just sent; the barrier orders LDS only -- the images and the operand slot)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lap(5);
+    }
+
+    // ---- initial Conv1D(32, 1): dW0[f][c] = sum_t x[t][f] g[t][c], db0[c] = sum_t g[t][c] -- exact-f32 products (k = 4 steps over the
+    // frames, X read from global memory as in tcn_backward_mfma_kernel); g goes to LDS as f32 rows of stride SX over the patch's images ----
+    const int RPm = 16 * geo.units;
+    if (has_tile) {
+        float *G = reinterpret_cast<float *>(img) + (size_t)t * SX;
+        *reinterpret_cast<f32x4 *>(G + 4 * q) = g0;
+        *reinterpret_cast<f32x4 *>(G + 16 + 4 * q) = g1;
+    }
+    __syncthreads();
+    const int fmt = (a.F + 15) >> 4;
+    for (int job = wave; job < fmt * 2 + 2; job += nw) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const bool bias = job >= fmt * 2;
+        const int mt = bias ? 0 : job >> 1, nt_ = bias ? job - fmt * 2 : job & 1;
+        const int f = 16 * mt + j;
+        for (int pp = 0; pp < g_here; ++pp) {
+            const float *G = reinterpret_cast<const float *>(smb + (size_t)pp * geo.per_patch);
+            const float *xcol = X + (size_t)(n0 + pp) * T * a.F + (f < a.F ? f : 0);
+            auto fetch = [&](int s, float (&av)[4]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kr = 4 * s + e + 4 * q;
+                    av[e] = bias ? 1.0f : ((kr < T && f < a.F) ? xcol[(size_t)kr * a.F] : 0.f);
+                }
+            };
+            float av[4];
+            fetch(0, av);
+            for (int s = 0; s < RPm / 4; s += 4) {
+                float an[4];
+                fetch(min(s + 4, RPm / 4 - 4), an);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    acc = mfma4(av[e], G[(size_t)(4 * s + e + 4 * q) * SX + 16 * nt_ + j], acc);
+                    acc2 = mfma4(av[e + 1], G[(size_t)(4 * s + e + 1 + 4 * q) * SX + 16 * nt_ + j], acc2);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = an[e];
+            }
+        }
+        acc += acc2;
+        if (bias) {
+            if (q == 0) gadd(grad, a.gq, a.off.w0_b + 16 * nt_ + j, acc[0]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ff = 16 * mt + 4 * q + r;
+                if (ff < a.F) gadd(grad, a.gq, a.off.w0_k + (size_t)ff * C + 16 * nt_ + j, acc[r]);
+            }
+        }
+    }
+    lap(6);
+    if (a.stamps && tid == 0 && (blockIdx.x % 32 == 0 || blockIdx.x == gridDim.x - 1)) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        printf("tcn_backward_bf16_kernel wg %d xcc %u: entry %llu exit %llu (x10 ns)\n", (int)blockIdx.x, xcc & 15u, t_entry, __builtin_amdgcn_s_memrealtime());
+    }
+    if (stamping)
+        printf("tcn_backward_bf16_kernel wg0 wave %d (x10 ns, summed over %d blocks): prologue %llu  A %llu  barrier1 %llu  B %llu  C %llu  barrier2 %llu  layer0 %llu\n",
+               wave, a.n_blocks, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+}
+
+constexpr size_t kLdsMax = 160 * 1024;
+
+bool bwd_geo(int T, int n_dil, BwdGeo *g) {
+    if (T < 1 || T > 128) return false;
+    g->units = (T + 15) / 16;
+    g->K32 = (16 * g->units + 31) / 32;
+    (void)n_dil;
+    g->halo = 8;
+    g->sxt = 2 * (2 * g->halo + 32 * g->K32) + 16;  // 16 x (3 + 4 K32): an odd multiple of 16 bytes
+    g->st = 2 * 32 * g->K32 + 16;
+    g->h_x = 32 * g->sxt, g->h_t = 32 * g->st, g->h_du = (T + 1) * kDuRow;
+    g->o_x = 0;
+    g->o_y = g->o_x + 2 * g->h_x;
+    g->o_g = g->o_y + 2 * g->h_t;
+    g->o_du_t = g->o_g + 2 * g->h_t;
+    g->o_du = g->o_du_t + 2 * g->h_t;
+    g->per_patch = g->o_du + 2 * g->h_du;
+    g->per_patch = (g->per_patch + 15) / 16 * 16;
+    if ((size_t)16 * g->units * SX * sizeof(float) > (size_t)g->per_patch) return false;  // the tail's f32 rows live on the patch's images
+    g->G = (size_t)2 * g->per_patch + 2 * kSlotHalf <= kLdsMax ? 2 : 1;
+    return (size_t)g->G * g->per_patch + 2 * kSlotHalf <= kLdsMax;
+}
+
+}  // namespace
+
+namespace smh_tcn {
+
+int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, const float *d_x, const float *d_flat,
+                         const float *d_acts, const float *d_drop_tcn, const float *d_dpre, float *d_grad, const float *d_upre,
+                         hipStream_t st) {
+    BwdGeo geo;
+    if (!bwd_geo(ba.T, ba.n_dil, &geo)) return kBwdBf16Unsupported;
+    if (const char *ev = getenv("SMH_BWD_BF16_G")) {  // tuning: patches per workgroup
+        if (atoi(ev) == 1) geo.G = 1;
+    }
+    const size_t need = (size_t)ba.n_blocks * 2 * kUnitsPerBlk * 64 * 16;
+    if (*pack_cap < need) {
+        if (*d_pack) SMH_CHECK_HIP(hipFree(*d_pack));
+        *d_pack = nullptr, *pack_cap = 0;
+        SMH_CHECK_HIP(hipMalloc(d_pack, need));
+        *pack_cap = need;
+    }
+    if (ba.n_blocks > 0) {
+        const int n = ba.n_blocks * kUnitsPerBlk * 64;
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_flat, ba.off, ba.n_blocks, (bf16x8 *)*d_pack);
+        int rc = smh::launch_status("pack_bwd_kernel");
+        if (rc) return rc;
+    }
+    const size_t lds = (size_t)geo.G * geo.per_patch + 2 * kSlotHalf;
+    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tcn_backward_bf16_kernel, dim3((ba.N + geo.G - 1) / geo.G), dim3(512 * geo.G), lds, st, ba, geo, d_x, d_flat,
+                       (const bf16x8 *)*d_pack, d_acts, d_drop_tcn, d_dpre, d_grad, d_upre);
+    return smh::launch_status("tcn_backward_bf16_kernel");
+}
+
+}  // namespace smh_tcn

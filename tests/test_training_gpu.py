@@ -315,6 +315,32 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
         assert np.abs(bn[hi * 32 + 16:hi * 32 + 32] - var).max() <= 1e-4 * max(1.0, np.abs(var).max())
 
 
+@pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68), (3, 3, 99), (3, 510, 68), (3, 4, 20), (3, 3, 128)])
+def test_bf16_backward_equals_the_f32_backward_on_the_same_forward(ncls, N, W, monkeypatch):
+    """dtype bf16 runs the residual blocks' backward on the bf16 matrix pipe with split operands (smh_train_bf16.hip); SMH_BWD_BF16=0
+    keeps the exact-f32 kernel behind the same bf16 forward.  Both read the gates that forward saved, so the two gradients are the
+    same function evaluated with f32-grade products in a different order: every tensor within 2e-4 relative L2 (measured ~1e-5) --
+    the backward's own arithmetic, apart from the gate-flip distance to the float64 oracle the tests above allow for.
+    W = 68: two patches per workgroup (N odd: a workgroup with one); 99, 128: one patch per workgroup; 20: two tiles, dilations >= W."""
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, drop_tcn, drop_heads = _problem(ncls, N, W=W, seed=5)
+    m = B3MTL(n_feat=240, patch_size=W, n_classes=ncls)
+    m.set_weights_dict(w)
+    m.train_dtype = "bf16"
+    dt, dh = torch.from_numpy(drop_tcn).cuda(), torch.from_numpy(drop_heads).cuda()
+    grads = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("SMH_BWD_BF16", env)
+        m.train_on_batch(x, y, drop_tcn=dt, drop_heads=dh, apply=False)
+        torch.cuda.synchronize()
+        grads.append(_flat_to_dict(m, m._grad_tensor().cpu().numpy().astype(np.float64)))
+    for name, gref in grads[0].items():
+        if name.endswith(tr.TRAINABLE_SKIP):
+            continue
+        rel = np.linalg.norm(grads[1][name] - gref) / max(np.linalg.norm(gref), 1e-12)
+        assert rel <= 2e-4 or np.abs(gref).max() < 1e-5, (name, rel)
+
+
 @pytest.mark.parametrize("ncls,N", [(3, 510), (5, 510), (3, 600)])   # 600: past the heads kernel's LDS tile (its other path)
 def test_deterministic_gradients_are_bit_reproducible(ncls, N):
     """`model.deterministic_gradients = True` (smh_trainer_set_deterministic): the weight-gradient contributions of the 510
