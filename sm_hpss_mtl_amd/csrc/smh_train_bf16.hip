@@ -94,11 +94,22 @@ struct BwdGeo {
     int per_patch;                    // bytes per patch
 };
 
-// wave -> weight-gradient tile job (phase B), a permutation of 0..15: job < 4: dW2 (mt = job / 2, nt = job % 2); else tap = (job - 4) / 4,
-// mt, nt.  The side-tap jobs (4..7, 12..15: funnel-shifted operand reads) go to the waves that own no 16-frame tile at W = 68
-// (5, 6, 7 of patch 0; 8, 14, 15 of patch 1) and to the two lone fifth tiles
-// (nibble w of the constant: a table in memory was a global load, and the vmcnt(0) behind it waited for the block's prefetch from HBM)
-constexpr unsigned long long kJobOfWave = 0xDCFBA987654E3210ull;  // waves 0..15: 0, 1, 2, 3, 14, 4, 5, 6, 7, 8, 9, 10, 11, 15, 12, 13
+// the part of the plan that follows from K32 alone, as compile-time constants (as kernel arguments every image offset became a
+// per-lane address register of its own, hoisted out of the block loop and spilled)
+template <int K32>
+struct GeoK {
+    static constexpr int halo = 8, sxt = 2 * (2 * halo + 32 * K32) + 16, st = 2 * 32 * K32 + 16;
+    static constexpr int h_x = 32 * sxt, h_t = 32 * st;
+    static constexpr int o_x = 0, o_y = o_x + 2 * h_x, o_g = o_y + 2 * h_t, o_du_t = o_g + 2 * h_t, o_du = o_du_t + 2 * h_t;
+    static_assert((sxt / 16) % 2 == 1 && (st / 16) % 2 == 1, "row strides: odd multiples of 16 bytes");
+};
+
+// wave -> weight-gradient item of phase B, nibble w of the constant: 0 = dW2, 1..3 = dW1 tap 0..2, 15 = none.  An item runs over ALL the
+// workgroup's patches before it sends its 18 atomic instructions: the atomics on the 4 176 gradient words of a block, which every
+// workgroup of the grid adds to within the same microsecond, are what the kernel waits for (timing probe: 100 us of 263 with one item
+// per kind and patch).  Two patches per workgroup (16 waves): waves 5..8, which own no 16-frame tile at W = 68.
+constexpr unsigned long long kItemOfWave2 = 0xFFFFFFF3120FFFFFull;  // waves 5..8: dW2, tap 1, tap 0, tap 2
+constexpr unsigned long long kItemOfWave1 = 0xFFFFFFFF3120FFFFull;  // one patch per workgroup (8 waves): waves 4..7
 
 // canonical f32 kernels -> split A operands, one thread per 16-byte unit: dst[blk][hi 512 | lo 512] with unit e = mt (W2: dyn[c] = sum_co
 // k2[c][co] g[co]) or 2 + 2 tap + mt (W1: dx[c] += sum_co k1[tap][c][co] du[t - off][co]); lane (i, kg) holds row c = 16 mt + i, columns
@@ -122,17 +133,59 @@ __global__ void pack_bwd_kernel(const float *__restrict__ flat, Offsets off, int
     dst[(size_t)blk * 2 * kUnitsPerBlk * 64 + kUnitsPerBlk * 64 + e * 64 + lane] = lo;
 }
 
-__global__ void __launch_bounds__(1024)
+// d loss / d (TCN output before its final relu), the gradient the block loop starts from:
+//   gt[n][k] = relu'(x_last[n][k]) * sum_o dpre[n][o] Wh[k][o],   k = frame * 32 + channel, o over [3C | Dense(16) of every head]
+// as its own small product (exact-f32 matrix instructions, M = 16 rows of k per workgroup, N = 16 patches per tile, K = the 51 / 69
+// outputs): inside the backward kernel every workgroup read all of Wh for its two patches -- 444 KB from L2, 35 us of prologue.
+constexpr int kDtSteps = (kPS + 3) / 4;
+__global__ void __launch_bounds__(256)
+dtrunk_kernel(BwdArgs a, const float *__restrict__ flatw, const float *__restrict__ acts, const float *__restrict__ dpre,
+              float *__restrict__ gt) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    const int k = 16 * blockIdx.x + j, nslot = a.n_blocks + 1, D = a.T * C;
+    float av[kDtSteps];
+#pragma unroll
+    for (int s = 0; s < kDtSteps; ++s) {
+        const int o = 4 * s + q;
+        float w = 0.f;
+        if (o < a.n_classes) w = flatw[a.off.c3_k + (size_t)k * a.n_classes + o];
+        else if (o < a.NH) w = flatw[a.off.head[(o - a.n_classes) / kHidden] + (size_t)k * kHidden + (o - a.n_classes) % kHidden];
+        av[s] = w;
+    }
+    const int tiles = (a.N + 15) / 16;
+    for (int pt = wave + 4 * blockIdx.y; pt < tiles; pt += 4 * gridDim.y) {
+        const int n = 16 * pt + j;
+        const bool valid = n < a.N;
+        float bv[kDtSteps];
+#pragma unroll
+        for (int s = 0; s < kDtSteps; ++s) bv[s] = (valid && 4 * s + q < a.NH) ? dpre[(size_t)n * kPS + 4 * s + q] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kDtSteps; ++s) acc = mfma4(av[s], bv[s], acc);
+        if (valid) {  // D[row 4 q + r of the k tile][patch j]
+            const int kk = 16 * blockIdx.x + 4 * q;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(acts + ((size_t)n * nslot + a.n_blocks) * D + kk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = x[r] > 0.f ? acc[r] : 0.f;
+            *reinterpret_cast<f32x4 *>(gt + (size_t)n * D + kk) = acc;
+        }
+    }
+}
+
+// STAMPS: tools only (SMH_BWD_STAMPS) -- the phase counters cost 20 registers, so they are an instantiation of their own
+template <int K32, int G, bool STAMPS>
+__global__ void __launch_bounds__(512 * G)
 tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, const float *__restrict__ flatw,
                          const bf16x8 *__restrict__ pk, const float *__restrict__ acts, const float *__restrict__ drop,
-                         const float *__restrict__ dpre, float *__restrict__ grad, const float *__restrict__ upre) {
+                         const float *__restrict__ gt, float *__restrict__ grad, const float *__restrict__ upre) {
     extern __shared__ __attribute__((aligned(16))) char smb[];
+    using GH = GeoK<K32>;
     const int T = a.T, nslot = a.n_blocks + 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int q = lane >> 4, j = lane & 15;
-    const int n0 = blockIdx.x * geo.G;
-    const int g_here = min(geo.G, a.N - n0);
+    const int n0 = blockIdx.x * G;
+    const int g_here = min(G, a.N - n0);
     // this wave's patch and 16-frame tile (patch 1's tiles sit one wave further on, so that the 5 + 5 tiles of two 68-frame patches
     // spread 3 / 3 / 2 / 2 over the four SIMDs)
     const int p = wave >> 3;
@@ -141,68 +194,47 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     const int t = 16 * u + j;
     const bool live = has_tile && t < T;
     char *img = smb + (size_t)p * geo.per_patch;
-    char *wslot = smb + (size_t)geo.G * geo.per_patch;
+    char *wslot = smb + (size_t)G * geo.per_patch;
 
     // tools only (SMH_BWD_STAMPS): waves 0 (owns a tile) and 5 (owns none at W = 68) of workgroup 0 print their phases, summed over the blocks
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-    const bool stamping = a.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5);
+    const bool stamping = STAMPS && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5);
     if (stamping) tlast = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long t_entry = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_entry = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     auto lap = [&](int i) {
+        if constexpr (!STAMPS) return;
         if (stamping) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             tph[i] += now - tlast;
             tlast = now;
         }
     };
-    for (int i = tid; i < geo.G * geo.per_patch / 16; i += nt) reinterpret_cast<u32x4s *>(smb)[i] = u32x4s{0u, 0u, 0u, 0u};
+    for (int i = tid; i < G * geo.per_patch / 16; i += nt) reinterpret_cast<u32x4s *>(smb)[i] = u32x4s{0u, 0u, 0u, 0u};
     // the block's operands: 16 pieces of 1 KiB (64 lanes x 16 bytes): hi W2 (0, 1), hi W1 (2..7), lo W2 (8, 9), lo W1 (10..15)
     auto stage_piece = [&](int blk, int piece) {
         const char *src = reinterpret_cast<const char *>(pk + (size_t)blk * 2 * kUnitsPerBlk * 64 + piece * 64 + lane);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(wslot + piece * 1024), 16, 0, 0);
     };
+    // The waves that carry a weight-gradient item (phase B) request nothing: a wave has to wait for its pieces with vmcnt(0), and for
+    // them that would be a wait for the round trips of their atomics -- on 4 176 words that every workgroup of the grid adds to
+    // within the same microsecond (timing probe: 100 of the kernel's 260 us when every barrier waited for them).
+    constexpr int kDmaWaves = G == 2 ? 12 : 4;
+    const int didx = G == 2 ? (wave < 5 ? wave : (wave >= 9 ? wave - 4 : -1)) : (wave < 4 ? wave : -1);
     auto stage_w2 = [&](int blk) {
-        for (int i = wave; i < 4; i += nw) stage_piece(blk, i < 2 ? i : 6 + i);
+        if (wave < 4) stage_piece(blk, wave < 2 ? wave : 6 + wave);
     };
     auto stage_w1 = [&](int blk) {
-        for (int i = wave; i < 12; i += nw) stage_piece(blk, i < 6 ? 2 + i : 4 + i);
+        if (didx >= 0)
+            for (int i = didx; i < 12; i += kDmaWaves) stage_piece(blk, i < 6 ? 2 + i : 4 + i);
     };
     if (a.n_blocks > 0) stage_w2(a.n_blocks - 1), stage_w1(a.n_blocks - 1);
 
-    // the selection operands of the transposing products: channel 16 h + n of the k' order sits at k' = 8 (n / 4) + 4 h + n % 4
-    bf16x8 sel[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sel[h][e] = (__bf16)((q == (j >> 2) && e == 4 * h + (j & 3)) ? 1.0f : 0.0f);
-
-    // ---- Dense-on-trunk backward: g = relu'(x_last) * (dpre @ Wh^T), in C layout, straight into the registers it lives in ----
+    // ---- d loss / d (TCN output), from dtrunk_kernel, in C layout: straight into the registers it lives in over the whole kernel ----
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const float *xp = acts + (((size_t)(n0 + p) * nslot + a.n_blocks) * T + t) * C + 4 * q;
-        const f32x4 xl0 = *reinterpret_cast<const f32x4 *>(xp), xl1 = *reinterpret_cast<const f32x4 *>(xp + 16);
-        const float *dp = dpre + (size_t)(n0 + p) * kPS;  // (wave-uniform)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4);
-            const size_t k = (size_t)t * C + c;
-            float acc = 0.f;
-            for (int o = 0; o < a.n_classes; ++o) acc = fmaf(dp[o], flatw[a.off.c3_k + k * a.n_classes + o], acc);
-            for (int h = 0; h < a.n_heads; ++h) {
-                const float *wr = flatw + a.off.head[h] + k * kHidden;
-#pragma unroll
-                for (int v4 = 0; v4 < kHidden / 4; ++v4) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wr + 4 * v4);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc = fmaf(dp[a.n_classes + h * kHidden + 4 * v4 + jj], w[jj], acc);
-                }
-            }
-            const float xv = e < 4 ? xl0[e] : xl1[e - 4];
-            const float gv = xv > 0.f ? acc : 0.f;
-            if (e < 4) g0[e] = gv;
-            else g1[e - 4] = gv;
-        }
+        const float *gp = gt + ((size_t)(n0 + p) * T + t) * C + 4 * q;
+        g0 = *reinterpret_cast<const f32x4 *>(gp), g1 = *reinterpret_cast<const f32x4 *>(gp + 16);
     }
 
     // register prefetch of a block's inputs for this lane's row: block input, saved dilated-conv output, dropout mask
@@ -226,7 +258,15 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
 
     // frame-contiguous images of eight values in C layout: two exact transposing products per half (hi, lo), packed back to bf16
     // (the upper halves of the f32 results), one 8-byte write each; e0 = element index of the tile's first frame in the row
-    auto transpose_store = [&](bf16x8 vh, bf16x8 vl, char *ih, char *il, int stride, int e0) {
+    // the selection operands: channel 16 h + n of the k' order sits at k' = 8 (n / 4) + 4 h + n % 4 (built where they are used: eight
+    // registers that would otherwise stay live across the weight-gradient phase)
+    auto make_sel = [&](bf16x8 (&sel)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sel[h][e] = (__bf16)((q == (j >> 2) && e == 4 * h + (j & 3)) ? 1.0f : 0.0f);
+    };
+    auto transpose_store = [&](const bf16x8 (&sel)[2], bf16x8 vh, bf16x8 vl, char *ih, char *il, int stride, int e0) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -253,11 +293,13 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
         if (blk < a.n_blocks - 1) stage_w1(blk);  // (phase C of the block before is behind the barrier)
         // ---- phase A ---------------------------------------------------------------------------------------------------------------
-        if (has_tile) {  // (wave-uniform)
+        if (has_tile && !(a.split3 & 4)) {  // (wave-uniform; the mask: timing probes)
             const f32x4 u0 = pf_u0, u1 = pf_u1, dm0 = pf_d0, dm1 = pf_d1;
+            bf16x8 sel[2];
+            make_sel(sel);
             bf16x8 vh, vl;
             split8(pf_x0, pf_x1, vh, vl);
-            transpose_store(vh, vl, img + geo.o_x, img + geo.o_x + geo.h_x, geo.sxt, geo.halo + 16 * u);
+            transpose_store(sel, vh, vl, img + GH::o_x, img + GH::o_x + GH::h_x, GH::sxt, GH::halo + 16 * u);
             float r0[4], r1[4], mx = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -273,10 +315,10 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
                 y1[r] = live ? r1[r] * inv_m * dm1[r] : 0.f;
             }
             split8(y0, y1, vh, vl);
-            transpose_store(vh, vl, img + geo.o_y, img + geo.o_y + geo.h_t, geo.st, 16 * u);
+            transpose_store(sel, vh, vl, img + GH::o_y, img + GH::o_y + GH::h_t, GH::st, 16 * u);
             bf16x8 gh, gl;
             split8(g0, g1, gh, gl);
-            transpose_store(gh, gl, img + geo.o_g, img + geo.o_g + geo.h_t, geo.st, 16 * u);
+            transpose_store(sel, gh, gl, img + GH::o_g, img + GH::o_g + GH::h_t, GH::st, 16 * u);
             // dyn[c][frame] = sum_co W2[c][co] g[frame][co]
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             d0 = product3(ld16(wslot + (0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (0 * 64 + lane) * 16), gh, gl, d0);
@@ -303,37 +345,38 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             }
             split8(du0, du1, vh, vl);
             if (live) {
-                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + geo.o_du + t * kDuRow + 16 * q, 16)) = vh;
-                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + geo.o_du + geo.h_du + t * kDuRow + 16 * q, 16)) = vl;
+                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + GH::o_du + t * kDuRow + 16 * q, 16)) = vh;
+                *reinterpret_cast<bf16x8 *>(__builtin_assume_aligned(img + GH::o_du + geo.h_du + t * kDuRow + 16 * q, 16)) = vl;
             }
-            transpose_store(vh, vl, img + geo.o_du_t, img + geo.o_du_t + geo.h_t, geo.st, 16 * u);
+            transpose_store(sel, vh, vl, img + GH::o_du_t, img + GH::o_du_t + GH::h_t, GH::st, 16 * u);
         }
         lap(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the dilated kernel have landed
-        __syncthreads();
+        if (didx >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the dilated kernel have landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads(): see the barrier at the end of the block)
         lap(2);
-        if (blk > 0) {
-            stage_w2(blk - 1);  // phase A was the 1x1 kernel's last reader
-            prefetch(blk - 1);
-        }
+        if (blk > 0) stage_w2(blk - 1);  // phase A was the 1x1 kernel's last reader
         // ---- phase B: weight gradients ---------------------------------------------------------------------------------------------
+        // item = dW2 | dW1 tap 0, 1, 2 over all the workgroup's patches: the whole 32 x 32 gradient as 2 x 2 accumulator tiles, so that a k step's eight
+        // operand reads feed twelve products (as sixteen 16 x 16 jobs of four reads per three products the phase sat on LDS bandwidth:
+        // 384 KB per block and CU)
         for (int slot = wave; slot < 16; slot += nw) {
-            const int job = (int)((kJobOfWave >> (4 * slot)) & 15ull);
-            int tap = 1, mt, nt_;
-            if (job < 4) mt = job >> 1, nt_ = job & 1;
-            else tap = (job - 4) >> 2, mt = ((job - 4) >> 1) & 1, nt_ = (job - 4) & 1;
-            const bool w2 = job < 4;
+            const int kind = (int)(((G == 2 ? kItemOfWave2 : kItemOfWave1) >> (4 * slot)) & 15ull);
+            if (kind == 15 || (a.split3 & 2)) continue;
+            const bool w2 = kind == 0;
+            const int tap = w2 ? 1 : kind - 1;
             const int off = w2 ? 0 : (tap - 1) * d;
             if (off != 0 && d >= T) continue;  // a side tap that only ever sees the zero padding
-            const bool bias = mt == 0 && tap == 1;
-            const int oA = w2 ? geo.o_y : geo.o_x, hA = w2 ? geo.h_t : geo.h_x, sA = w2 ? geo.st : geo.sxt;
-            const int oB = w2 ? geo.o_g : geo.o_du_t;
-            const int eA = (w2 ? 0 : geo.halo) + 8 * q + off;  // element index of this lane's first frame in its A row
-            const int arow = oA + (16 * mt + j) * sA;  // (its first 16 bytes: the zero halo chunk of an xT row)
-            const int aoff = arow + 2 * (eA & ~1), boff = oB + (16 * nt_ + j) * geo.st + 16 * q;
+            const bool bias = tap == 1;        // dW2: db2 = column sums of g; centre tap: db1 = column sums of du
+            const int oA = w2 ? GH::o_y : GH::o_x, hA = w2 ? GH::h_t : GH::h_x, sA = w2 ? GH::st : GH::sxt;
+            const int oB = w2 ? GH::o_g : GH::o_du_t;
+            const int eA = (w2 ? 0 : GH::halo) + 8 * q + off;  // element index of this lane's first frame in its A row
+            const int arow = oA + j * sA;                       // (its first 16 bytes: the zero halo chunk of an xT row)
+            const int aoff = arow + 2 * (eA & ~1), boff = oB + j * GH::st + 16 * q;
             const unsigned sh = (eA & 1) ? 16u : 0u;
             const bool aligned = (off & 7) == 0;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[2][2], accb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x8 ones;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -349,23 +392,39 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
                                                                  __builtin_amdgcn_alignbit(w3, w2_, sh), __builtin_amdgcn_alignbit(w4, w3, sh)});
                     }
                 };
-                for (int pp = 0; pp < g_here; ++pp) {
+                // (one step's 32 operand registers at a time: unrolled, the steps' loads were hoisted together and spilled)
+#pragma unroll 1
+                for (int ps = 0; ps < g_here * K32; ++ps) {
+                    const int pp = ps >= K32 ? 1 : 0, s = ps - pp * K32;
                     const char *ip = smb + (size_t)pp * geo.per_patch;
-                    for (int s = 0; s < geo.K32; ++s) {
-                        const char *pa = ip + aoff + 64 * s;
-                        if constexpr (AL) {
-                            // an aligned tap moves whole 8-frame chunks: one outside the patch's 32 K32 frames is zero (the halo chunk
-                            // at the start of the row), a step with all four chunks outside is skipped (d = 64 at W = 68: two of three)
-                            if (32 * s + off + 24 < 0 || 32 * s + off >= 32 * geo.K32) continue;  // (uniform)
-                            const bool ok = (unsigned)(32 * s + 8 * q + off) < (unsigned)(32 * geo.K32);
-                            pa = ok ? pa : ip + arow;
-                        }
-                        const bf16x8 ah = lda(pa), al = lda(pa + hA);
-                        const bf16x8 bh = ld16(ip + boff + 64 * s), bl = ld16(ip + boff + geo.h_t + 64 * s);
-                        acc = product3(ah, al, bh, bl, acc);
-                        if (bias) {  // (uniform) column sums of B: the bias gradient of this column tile
-                            accb = mfma_bf16(ones, bl, accb);
-                            accb = mfma_bf16(ones, bh, accb);
+                    const char *pa = ip + aoff + 64 * s;
+                    bool ok = true;
+                    if constexpr (AL) {
+                        // an aligned tap moves whole 8-frame chunks: one outside the patch's 32 K32 frames is zero (the halo chunk at the
+                        // start of the row), a step with all four chunks outside is skipped (d = 64 at W = 68: two of three)
+                        if (32 * s + off + 24 < 0 || 32 * s + off >= 32 * K32) continue;  // (uniform)
+                        ok = (unsigned)(32 * s + 8 * q + off) < (unsigned)(32 * K32);
+                    }
+                    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const char *pm = ok ? pa + 16 * mt * sA : ip + arow + 16 * mt * sA;
+                        ah[mt] = lda(pm), al[mt] = lda(pm + hA);
+                    }
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        const char *pb = ip + boff + 16 * n2 * GH::st + 64 * s;
+                        bh[n2] = ld16(pb), bl[n2] = ld16(pb + GH::h_t);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) acc[mt][n2] = product3(ah[mt], al[mt], bh[n2], bl[n2], acc[mt][n2]);
+                    if (bias) {  // (uniform) column sums of B
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) {
+                            accb[n2] = mfma_bf16(ones, bl[n2], accb[n2]);
+                            accb[n2] = mfma_bf16(ones, bh[n2], accb[n2]);
                         }
                     }
                 }
@@ -373,29 +432,41 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             if (aligned) run(std::true_type{});
             else run(std::false_type{});
             const unsigned gbase = (unsigned)(w2 ? o_k2 : o_k1 + (size_t)tap * C * C), gbias = (unsigned)(w2 ? o_b2 : o_b1);
-            // the pieces of the next block's 1x1 kernel this wave requested at the top of the phase have landed by now; waiting here, IN
-            // FRONT of the atomics, keeps their round trips out of the wait (vmcnt counts them too) -- the barrier below needs no wait
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (a.split3 & 1) continue;  // (timing probe)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gadd(grad, a.gq, gbase + (unsigned)((16 * mt + 4 * q + r) * C + 16 * nt_ + j), acc[r]);
-            if (bias && q == 0) gadd(grad, a.gq, gbias + 16 * nt_ + j, accb[0]);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gadd(grad, a.gq, gbase + (unsigned)((16 * mt + 4 * q + r) * C + 16 * n2 + j), acc[mt][n2][r]);
+            if (bias && q == 0) {
+                gadd(grad, a.gq, gbias + j, accb[0][0]);
+                gadd(grad, a.gq, gbias + 16 + j, accb[1][0]);
+            }
         }
+        // (behind phase B: its 24 registers would be live across the items' 2 x 2 accumulators and operands; the waves that own whole
+        // tiles have no item and get here straight from the barrier)
+        if (blk > 0) prefetch(blk - 1);
         lap(3);
         // ---- phase C: g[frame][c] += sum_tap sum_co W1[tap][c][co] du[frame - off][co] ------------------------------------------
-        if (has_tile) {
+        if (has_tile && !(a.split3 & 8)) {
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const int off = (tap - 1) * d;
                 const bool ok = (t - off >= 0) && (t - off < T);
                 if (tap != 1 && !__any(ok)) continue;
                 const int row = ok ? t - off : T;  // row T of the du images stays zero
-                const bf16x8 bh = ld16(img + geo.o_du + row * kDuRow + 16 * q), bl = ld16(img + geo.o_du + geo.h_du + row * kDuRow + 16 * q);
+                const bf16x8 bh = ld16(img + GH::o_du + row * kDuRow + 16 * q), bl = ld16(img + GH::o_du + geo.h_du + row * kDuRow + 16 * q);
                 const int e0 = 2 + 2 * tap;
                 g0 = product3(ld16(wslot + (e0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (e0 * 64 + lane) * 16), bh, bl, g0);
                 g1 = product3(ld16(wslot + ((e0 + 1) * 64 + lane) * 16), ld16(wslot + kSlotHalf + ((e0 + 1) * 64 + lane) * 16), bh, bl, g1);
             }
             if (!live) g0 = g1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // the pieces of the next block's 1x1 kernel requested at the top of phase B have landed (these waves send no atomics at two
+        // patches per workgroup; at one, theirs went out a phase ago)
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lap(4);
         // (not __syncthreads(): its workgroup-scope fence is an s_waitcnt vmcnt(0), i.e. a wait for the round trips of the weight-gradient
         // atomics this wave has just sent; the barrier orders LDS only -- the images and the operand slot)
@@ -407,9 +478,9 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     // frames, X read from global memory as in tcn_backward_mfma_kernel); g goes to LDS as f32 rows of stride SX over the patch's images ----
     const int RPm = 16 * geo.units;
     if (has_tile) {
-        float *G = reinterpret_cast<float *>(img) + (size_t)t * SX;
-        *reinterpret_cast<f32x4 *>(G + 4 * q) = g0;
-        *reinterpret_cast<f32x4 *>(G + 16 + 4 * q) = g1;
+        float *Gs = reinterpret_cast<float *>(img) + (size_t)t * SX;
+        *reinterpret_cast<f32x4 *>(Gs + 4 * q) = g0;
+        *reinterpret_cast<f32x4 *>(Gs + 16 + 4 * q) = g1;
     }
     __syncthreads();
     const int fmt = (a.F + 15) >> 4;
@@ -419,7 +490,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         const int mt = bias ? 0 : job >> 1, nt_ = bias ? job - fmt * 2 : job & 1;
         const int f = 16 * mt + j;
         for (int pp = 0; pp < g_here; ++pp) {
-            const float *G = reinterpret_cast<const float *>(smb + (size_t)pp * geo.per_patch);
+            const float *Gs = reinterpret_cast<const float *>(smb + (size_t)pp * geo.per_patch);
             const float *xcol = X + (size_t)(n0 + pp) * T * a.F + (f < a.F ? f : 0);
             auto fetch = [&](int s, float (&av)[4]) {
 #pragma unroll
@@ -435,8 +506,8 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
                 fetch(min(s + 4, RPm / 4 - 4), an);
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
-                    acc = mfma4(av[e], G[(size_t)(4 * s + e + 4 * q) * SX + 16 * nt_ + j], acc);
-                    acc2 = mfma4(av[e + 1], G[(size_t)(4 * s + e + 1 + 4 * q) * SX + 16 * nt_ + j], acc2);
+                    acc = mfma4(av[e], Gs[(size_t)(4 * s + e + 4 * q) * SX + 16 * nt_ + j], acc);
+                    acc2 = mfma4(av[e + 1], Gs[(size_t)(4 * s + e + 1 + 4 * q) * SX + 16 * nt_ + j], acc2);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = an[e];
@@ -454,10 +525,10 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         }
     }
     lap(6);
-    if (a.stamps && tid == 0 && (blockIdx.x % 32 == 0 || blockIdx.x == gridDim.x - 1)) {
+    if (STAMPS && tid == 0 && (blockIdx.x % 32 == 0 || blockIdx.x == gridDim.x - 1)) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        printf("tcn_backward_bf16_kernel wg %d xcc %u: entry %llu exit %llu (x10 ns)\n", (int)blockIdx.x, xcc & 15u, t_entry, __builtin_amdgcn_s_memrealtime());
+        printf("tcn_backward_bf16_kernel wg %d xcc %u: entry %llu exit %llu (x10 ns)\n", (int)blockIdx.x, xcc & 15u, t_entry, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     if (stamping)
         printf("tcn_backward_bf16_kernel wg0 wave %d (x10 ns, summed over %d blocks): prologue %llu  A %llu  barrier1 %llu  B %llu  C %llu  barrier2 %llu  layer0 %llu\n",
@@ -496,26 +567,46 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
                          hipStream_t st) {
     BwdGeo geo;
     if (!bwd_geo(ba.T, ba.n_dil, &geo)) return kBwdBf16Unsupported;
-    if (const char *ev = getenv("SMH_BWD_BF16_G")) {  // tuning: patches per workgroup
-        if (atoi(ev) == 1) geo.G = 1;
-    }
-    const size_t need = (size_t)ba.n_blocks * 2 * kUnitsPerBlk * 64 * 16;
+    BwdArgs bp = ba;
+    bp.split3 = 0;  // this kernel's timing-probe mask (results invalid): 1 no atomics, 2 no phase B, 4 no phase A, 8 no phase C
+    if (const char *ev = smh::probe_env("SMH_BWD_PROBE")) bp.split3 = atoi(ev);
+    SMH_REQUIRE(ba.NH <= kPS, "launch_backward_bf16: %d Dense-on-trunk outputs exceed the %d of a dpre row", ba.NH, kPS);
+    // workspace: [the blocks' kernels as split A operands | gt (N, T, 32)]
+    const size_t pack_bytes = ((size_t)ba.n_blocks * 2 * kUnitsPerBlk * 64 * 16 + 255) / 256 * 256;
+    const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float);
     if (*pack_cap < need) {
         if (*d_pack) SMH_CHECK_HIP(hipFree(*d_pack));
         *d_pack = nullptr, *pack_cap = 0;
         SMH_CHECK_HIP(hipMalloc(d_pack, need));
         *pack_cap = need;
     }
+    float *d_gt = reinterpret_cast<float *>(static_cast<char *>(*d_pack) + pack_bytes);
     if (ba.n_blocks > 0) {
         const int n = ba.n_blocks * kUnitsPerBlk * 64;
         hipLaunchKernelGGL(pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_flat, ba.off, ba.n_blocks, (bf16x8 *)*d_pack);
         int rc = smh::launch_status("pack_bwd_kernel");
         if (rc) return rc;
     }
+    {
+        const int tiles = (ba.N + 15) / 16;
+        hipLaunchKernelGGL(dtrunk_kernel, dim3(ba.T * C / 16, std::max(1, std::min(8, tiles / 16))), dim3(256), 0, st, ba, d_flat, d_acts, d_dpre, d_gt);
+        int rc = smh::launch_status("dtrunk_kernel");
+        if (rc) return rc;
+    }
     const size_t lds = (size_t)geo.G * geo.per_patch + 2 * kSlotHalf;
-    SMH_CHECK_HIP(hipFuncSetAttribute((const void *)tcn_backward_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tcn_backward_bf16_kernel, dim3((ba.N + geo.G - 1) / geo.G), dim3(512 * geo.G), lds, st, ba, geo, d_x, d_flat,
-                       (const bf16x8 *)*d_pack, d_acts, d_drop_tcn, d_dpre, d_grad, d_upre);
+    auto go = [&](auto kern) -> int {
+        SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((ba.N + geo.G - 1) / geo.G), dim3(512 * geo.G), lds, st, bp, geo, d_x, d_flat, (const bf16x8 *)*d_pack,
+                           d_acts, d_drop_tcn, (const float *)d_gt, d_grad, d_upre);
+        return SMH_OK;
+    };
+    int rc;
+    if (geo.K32 == 3 && geo.G == 2) rc = ba.stamps ? go(tcn_backward_bf16_kernel<3, 2, true>) : go(tcn_backward_bf16_kernel<3, 2, false>);
+    else if (geo.K32 == 1 && geo.G == 2) rc = go(tcn_backward_bf16_kernel<1, 2, false>);
+    else if (geo.K32 == 2 && geo.G == 2) rc = go(tcn_backward_bf16_kernel<2, 2, false>);
+    else if (geo.K32 == 4 && geo.G == 1) rc = go(tcn_backward_bf16_kernel<4, 1, false>);
+    else return kBwdBf16Unsupported;
+    if (rc) return rc;
     return smh::launch_status("tcn_backward_bf16_kernel");
 }
 
