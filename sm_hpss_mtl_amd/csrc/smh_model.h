@@ -42,6 +42,8 @@ struct TrainIO {
     float *pre;             // (N, kPS): Dense-on-trunk outputs incl. bias (3C logits | head Dense(16)s)
     float *upre;            // (N, n_blocks, T, 32): every block's dilated-conv output incl. bias, before the relu -- the gates of
                             // the backward's relu / channel-max normalisation (it used to recompute them: 48 products per tile)
+    int acts_last_only;     // (split-bf16 forward only) save slot n_blocks of `acts` alone: the split-bf16 backward rebuilds every
+                            // block's input from its output (x_b = x_b+1 - W2 . y_b - b2), half of the saved bytes never move
 };
 
 // heads_train_kernel (smh_train.hip): batch-statistics BN, Dropout, the four losses and d loss / d pre for the '3C'
@@ -98,6 +100,7 @@ Offsets offsets(const smh_model *m);
 void fill_args(const smh_model *m, int N, TcnArgs *a, size_t *lds);
 int repack(smh_model *m, hipStream_t st);  // d_flat -> packed operand buffers
 int launch_forward_bf16_train(smh_model *m, const float *d_x, int N, const TrainIO *tio, hipStream_t st);  // smh_tcn_bf16.hip
+bool backward_bf16_supported(int T, int n_dil);  // smh_train_bf16.hip: the patch geometry fits the split-bf16 backward's LDS plan
 int launch_forward(const smh_model *m, const float *d_x, int N, float *d_out, float *d_trunk, const TrainIO *tio,
                    hipStream_t st, int from_x0 = 0, int x0_shift = 0, int x0_T = 0);
 // smh_model_cfg.block_variant = 1 (smh_tcn_v2.hip): the two-convolution residual block of keras-tcn >= 2.8, inference only

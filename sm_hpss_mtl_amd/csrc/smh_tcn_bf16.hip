@@ -785,7 +785,7 @@ b3mtl_forward_bf16s_kernel(TcnArgs a, PackInfo pi, Offsets off, const float *__r
             const bf16x8 *w = wslot + (size_t)(blk & 1) * 2 * kSlotOps;
             TrainBlk tb{nullptr, nullptr, 0, 0, GR};
             if constexpr (TRAIN) {
-                save_acts(blk);
+                if (!tio.acts_last_only) save_acts(blk);
                 tb.ustride = a.n_blocks * T * C, tb.dstride = a.n_blocks * C;
                 tb.upre = tio.upre ? tio.upre + (size_t)n0 * tb.ustride + (size_t)blk * T * C : nullptr;
                 tb.drop = tio.drop_tcn ? tio.drop_tcn + (size_t)n0 * tb.dstride + (size_t)blk * C : nullptr;
@@ -947,7 +947,7 @@ static int forward_bf16(smh_model *m, const float *d_x, int N, float *d_out, int
         SMH_REQUIRE(lds_s <= 156 * 1024, "patch_size %d too long for the LDS-resident split-bf16 TCN", a.T);
         SMH_REQUIRE((size_t)pi.steps0 * 2 * 64 * 2 * 16 <= 2 * (size_t)(a.GRP + 1) * kRS * sizeof(__bf16) || from_x0,
                     "smh_model_forward_bf16: n_feat=%d too wide for the layer-0 operand staging", m->cfg.n_feat);
-        const TrainIO io = tio ? *tio : TrainIO{nullptr, nullptr, nullptr, nullptr};
+        const TrainIO io = tio ? *tio : TrainIO{nullptr, nullptr, nullptr, nullptr, 0};
 #define SMH_LAUNCH_BF16S(MT, TR)                                                                                                       \
     do {                                                                                                                              \
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)b3mtl_forward_bf16s_kernel<MT, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, \

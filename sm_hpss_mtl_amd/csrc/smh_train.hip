@@ -1369,7 +1369,11 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     smh_model *m = t->m;
     hipStream_t st = (hipStream_t)stream;
     SMH_CHECK_HIP(hipMemsetAsync(t->d_grad, 0, m->n_params * sizeof(float), st));
-    TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre, t->d_upre};
+    // dtype 1: the residual blocks' backward on the bf16 matrix pipe (smh_train_bf16.hip); patch geometries outside its LDS plan, and
+    // SMH_BWD_BF16=0 (A/B and tests), keep the exact-f32 kernel behind the bf16 forward -- which then has to save every block's input
+    const bool bf16_bwd = t->dtype == 1 && !getenv("SMH_TRAIN_VALU") && !(getenv("SMH_BWD_BF16") && atoi(getenv("SMH_BWD_BF16")) == 0) &&
+                          backward_bf16_supported(m->cfg.patch_size, m->cfg.n_dilations);
+    TrainIO tio{t->d_acts, d_drop_tcn, t->d_pre, t->d_upre, bf16_bwd ? 1 : 0};
     // dtype 1: the training forward on the bf16 matrix pipe (split operands: f32-grade products, smh_tcn_bf16.hip); it saves the
     // same activations and gates in f32, so the backward pass below is unchanged
     int rc = t->dtype == 1 ? launch_forward_bf16_train(m, d_x, N, &tio, st) : launch_forward(m, d_x, N, t->d_scratch_out, nullptr, &tio, st);
@@ -1411,14 +1415,12 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     const size_t lds_m = sizeof(float) * ((size_t)4 * RPm * SX + 4 * C * kWS + kMG * kPS + C + kZW);
     const size_t lds_long = sizeof(float) * ((size_t)4 * RPm * SX + kMG * kPS + C + kZW);  // kernels stay in global memory
     const bool short_ok = lds_m <= 156 * 1024 && ba.T <= kMfmaMaxT, long_ok = lds_long <= 156 * 1024 && ba.T <= kMfmaLongT;
-    // dtype 1: the residual blocks' backward on the bf16 matrix pipe (smh_train_bf16.hip); patch geometries outside its LDS plan, and
-    // SMH_BWD_BF16=0 (A/B and tests), keep the exact-f32 kernel behind the bf16 forward
     bool bwd_done = false;
-    if (t->dtype == 1 && !getenv("SMH_TRAIN_VALU") && !(getenv("SMH_BWD_BF16") && atoi(getenv("SMH_BWD_BF16")) == 0)) {
+    if (bf16_bwd) {
         rc = launch_backward_bf16(ba, &t->d_bwd_pack, &t->bwd_pack_cap, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,
                                   (const float *)t->d_upre, st);
-        if (rc == SMH_OK) bwd_done = true;
-        else if (rc != kBwdBf16Unsupported) return rc;
+        if (rc) return rc;
+        bwd_done = true;
     }
     if (bwd_done || ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU"))) {
         const dim3 grid((N + kMG - 1) / kMG);

@@ -79,8 +79,13 @@ __device__ __forceinline__ float quad_reduce(float v, F f) {
 }
 
 constexpr int kDuRow = 80;       // bytes per row of the du images: 32 bf16 + 16 bytes of padding (smh_tcn_bf16.hip: kRS)
-constexpr int kSlotHalf = 8192;  // bytes of hi operands in the slot (8 units x 64 lanes x 16 bytes), then the lo operands
-constexpr int kUnitsPerBlk = 8;  // operand units per block: W2 [mt] (2), W1 [tap][mt] (6)
+// The block's operand slot (and its image in the packed buffer), in pieces of 1 KiB = 64 lanes x 16 bytes: hi units 0..9, the 1x1
+// bias b2 as 32 raw floats, lo units 0..9.  Units: 0, 1 = W2 [mt] for dyn (canonical rows), 2..7 = W1 [tap][mt], 8, 9 = W2 [mt] in the
+// forward's orientation (rows = output channel), for x_b = x_b+1 - W2 . y_b - b2.
+constexpr int kUnitsPerBlk = 10;
+constexpr int kBiasPiece = kUnitsPerBlk, kLoPiece = kUnitsPerBlk + 1, kSlotPieces = 2 * kUnitsPerBlk + 1;
+constexpr int kSlotLo = kLoPiece * 1024;          // byte offset of the lo units
+constexpr int kSlotBytes = kSlotPieces * 1024;
 
 // LDS plan (host: bwd_geo)
 struct BwdGeo {
@@ -116,52 +121,71 @@ constexpr unsigned long long kItemOfWave1 = 0xFFFFFFFF3120FFFFull;  // one patch
 // co in the accumulator's channel order k' = 8 kg + e'
 __global__ void pack_bwd_kernel(const float *__restrict__ flat, Offsets off, int n_blocks, bf16x8 *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_blocks * kUnitsPerBlk * 64) return;
-    const int blk = idx / (kUnitsPerBlk * 64), e = (idx >> 6) % kUnitsPerBlk, lane = idx & 63, i = lane & 15, kg = lane >> 4;
+    if (idx >= n_blocks * (kUnitsPerBlk + 1) * 64) return;
+    const int blk = idx / ((kUnitsPerBlk + 1) * 64), e = (idx >> 6) % (kUnitsPerBlk + 1), lane = idx & 63, i = lane & 15, kg = lane >> 4;
     const size_t wo = off.blk0 + (size_t)blk * off.blk_stride;
-    const float *src;
-    if (e < 2) src = flat + wo + 3 * C * C + C + (size_t)(16 * e + i) * C;
-    else src = flat + wo + ((size_t)((e - 2) >> 1) * C + 16 * ((e - 2) & 1) + i) * C;
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(src + 4 * kg), b = *reinterpret_cast<const f32x4 *>(src + 16 + 4 * kg);
-    bf16x8 hi, lo;
+    const float *k1 = flat + wo, *k2 = flat + wo + 3 * C * C + C, *b2 = k2 + C * C;
+    bf16x8 *d = dst + (size_t)blk * kSlotPieces * 64;
+    if (e == kBiasPiece) {  // 32 raw floats in the first 8 units of the piece
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 8) v = *reinterpret_cast<const f32x4 *>(b2 + 4 * lane);
+        *reinterpret_cast<f32x4 *>(d + kBiasPiece * 64 + lane) = v;
+        return;
+    }
+    float vf[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float v = k < 4 ? a[k] : b[k - 4];
-        hi[k] = (__bf16)v, lo[k] = (__bf16)(v - (float)hi[k]);
+        const int ch = k < 4 ? 4 * kg + k : 16 + 4 * kg + (k - 4);  // the accumulator's channel order k'
+        if (e < 2) vf[k] = k2[(size_t)(16 * e + i) * C + ch];                                        // dyn[c] = sum_co k2[c][co] g[co]
+        else if (e < 8) vf[k] = k1[((size_t)((e - 2) >> 1) * C + 16 * ((e - 2) & 1) + i) * C + ch];  // dx[c] += sum_co k1[tap][c][co] du[co]
+        else vf[k] = k2[(size_t)ch * C + 16 * (e - 8) + i];                                          // o[co] = sum_c k2[c][co] y[c]
     }
-    dst[(size_t)blk * 2 * kUnitsPerBlk * 64 + e * 64 + lane] = hi;
-    dst[(size_t)blk * 2 * kUnitsPerBlk * 64 + kUnitsPerBlk * 64 + e * 64 + lane] = lo;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hi[k] = (__bf16)vf[k], lo[k] = (__bf16)(vf[k] - (float)hi[k]);
+    d[e * 64 + lane] = hi;
+    d[kLoPiece * 64 + e * 64 + lane] = lo;
 }
 
 // d loss / d (TCN output before its final relu), the gradient the block loop starts from:
 //   gt[n][k] = relu'(x_last[n][k]) * sum_o dpre[n][o] Wh[k][o],   k = frame * 32 + channel, o over [3C | Dense(16) of every head]
 // as its own small product (exact-f32 matrix instructions, M = 16 rows of k per workgroup, N = 16 patches per tile, K = the 51 / 69
 // outputs): inside the backward kernel every workgroup read all of Wh for its two patches -- 444 KB from L2, 35 us of prologue.
-constexpr int kDtSteps = (kPS + 3) / 4;
+// The order of the k index is free as long as both operands use the same one: lane group q takes outputs 4 q .. 4 q + 3 of a head's
+// sixteen in four consecutive steps, so that its A operands (a row of the head's Dense kernel) and its B operands (a row of dpre)
+// are one 16-byte load per head instead of four scalar ones; the 3 / 5 class outputs take one / two steps of scalar loads.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 __global__ void __launch_bounds__(256)
 dtrunk_kernel(BwdArgs a, const float *__restrict__ flatw, const float *__restrict__ acts, const float *__restrict__ dpre,
               float *__restrict__ gt) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
     const int k = 16 * blockIdx.x + j, nslot = a.n_blocks + 1, D = a.T * C;
-    float av[kDtSteps];
+    f32x4 ah[kMaxHeads];
+    float ac[2];
 #pragma unroll
-    for (int s = 0; s < kDtSteps; ++s) {
-        const int o = 4 * s + q;
-        float w = 0.f;
-        if (o < a.n_classes) w = flatw[a.off.c3_k + (size_t)k * a.n_classes + o];
-        else if (o < a.NH) w = flatw[a.off.head[(o - a.n_classes) / kHidden] + (size_t)k * kHidden + (o - a.n_classes) % kHidden];
-        av[s] = w;
-    }
+    for (int h = 0; h < kMaxHeads; ++h)
+        ah[h] = h < a.n_heads ? f32x4(*reinterpret_cast<const f32x4u *>(flatw + a.off.head[h] + (size_t)k * kHidden + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) ac[c] = 4 * c + q < a.n_classes ? flatw[a.off.c3_k + (size_t)k * a.n_classes + 4 * c + q] : 0.f;
     const int tiles = (a.N + 15) / 16;
     for (int pt = wave + 4 * blockIdx.y; pt < tiles; pt += 4 * gridDim.y) {
         const int n = 16 * pt + j;
         const bool valid = n < a.N;
-        float bv[kDtSteps];
+        const float *dp = dpre + (size_t)(valid ? n : 0) * kPS;
+        f32x4 bh[kMaxHeads];
+        float bc[2];
 #pragma unroll
-        for (int s = 0; s < kDtSteps; ++s) bv[s] = (valid && 4 * s + q < a.NH) ? dpre[(size_t)n * kPS + 4 * s + q] : 0.f;
+        for (int h = 0; h < kMaxHeads; ++h)
+            bh[h] = (valid && h < a.n_heads) ? f32x4(*reinterpret_cast<const f32x4u *>(dp + a.n_classes + h * kHidden + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bc[c] = (valid && 4 * c + q < a.n_classes) ? dp[4 * c + q] : 0.f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < kDtSteps; ++s) acc = mfma4(av[s], bv[s], acc);
+        for (int c = 0; c < 2; ++c) acc = mfma4(ac[c], bc[c], acc);
+#pragma unroll
+        for (int h = 0; h < kMaxHeads; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma4(ah[h][e], bh[h][e], acc);
         if (valid) {  // D[row 4 q + r of the k tile][patch j]
             const int kk = 16 * blockIdx.x + 4 * q;
             const f32x4 x = *reinterpret_cast<const f32x4 *>(acts + ((size_t)n * nslot + a.n_blocks) * D + kk);
@@ -185,6 +209,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int q = lane >> 4, j = lane & 15;
     const int n0 = blockIdx.x * G;
+    if (a.split3 & 16) grad = const_cast<float *>(gt) + (size_t)a.N * T * C + (size_t)(blockIdx.x & 7) * (1u << 20);  // (timing probe)
     const int g_here = min(G, a.N - n0);
     // this wave's patch and 16-frame tile (patch 1's tiles sit one wave further on, so that the 5 + 5 tiles of two 68-frame patches
     // spread 3 / 3 / 2 / 2 over the four SIMDs)
@@ -212,7 +237,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     for (int i = tid; i < G * geo.per_patch / 16; i += nt) reinterpret_cast<u32x4s *>(smb)[i] = u32x4s{0u, 0u, 0u, 0u};
     // the block's operands: 16 pieces of 1 KiB (64 lanes x 16 bytes): hi W2 (0, 1), hi W1 (2..7), lo W2 (8, 9), lo W1 (10..15)
     auto stage_piece = [&](int blk, int piece) {
-        const char *src = reinterpret_cast<const char *>(pk + (size_t)blk * 2 * kUnitsPerBlk * 64 + piece * 64 + lane);
+        const char *src = reinterpret_cast<const char *>(pk + ((size_t)blk * kSlotPieces + piece) * 64 + lane);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(wslot + piece * 1024), 16, 0, 0);
     };
@@ -221,12 +246,18 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     // within the same microsecond (timing probe: 100 of the kernel's 260 us when every barrier waited for them).
     constexpr int kDmaWaves = G == 2 ? 12 : 4;
     const int didx = G == 2 ? (wave < 5 ? wave : (wave >= 9 ? wave - 4 : -1)) : (wave < 4 ? wave : -1);
+    // what phase A reads: both orientations of the 1x1 kernel and its bias (nine pieces, waves 0..3) ...
     auto stage_w2 = [&](int blk) {
-        if (wave < 4) stage_piece(blk, wave < 2 ? wave : 6 + wave);
+        if (wave < 4)
+            for (int i = wave; i < 9; i += 4) {
+                const int unit = i < 5 ? (i < 2 ? i : 6 + i) : (i < 7 ? i - 5 : i + 1);  // hi 0, 1, 8, 9, bias (= 10); lo 0, 1, 8, 9
+                stage_piece(blk, i < 5 ? unit : kLoPiece + unit);
+            }
     };
+    // ... and what phase C reads: the dilated kernel (twelve pieces)
     auto stage_w1 = [&](int blk) {
         if (didx >= 0)
-            for (int i = didx; i < 12; i += kDmaWaves) stage_piece(blk, i < 6 ? 2 + i : 4 + i);
+            for (int i = didx; i < 12; i += kDmaWaves) stage_piece(blk, i < 6 ? 2 + i : kLoPiece + 2 + (i - 6));
     };
     if (a.n_blocks > 0) stage_w2(a.n_blocks - 1), stage_w1(a.n_blocks - 1);
 
@@ -237,15 +268,22 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         g0 = *reinterpret_cast<const f32x4 *>(gp), g1 = *reinterpret_cast<const f32x4 *>(gp + 16);
     }
 
-    // register prefetch of a block's inputs for this lane's row: block input, saved dilated-conv output, dropout mask
-    f32x4 pf_x0, pf_x1, pf_u0, pf_u1, pf_d0, pf_d1;
+    // x: the residual stream at this lane's row, walked backwards: it starts as the TCN output (slot n_blocks of `acts`, the only slot
+    // the forward saves for this kernel) and becomes every block's input in turn, x_b = x_b+1 - (W2 . y_b + b2) -- y_b is rebuilt from the
+    // saved conv output anyway, the six products cost less than reading (and the forward writing) 111 MB of saved block inputs, and
+    // what the subtraction loses (an ulp of x per block) is far below the split products' own 1e-5
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *xp = acts + (((size_t)(n0 + p) * nslot + a.n_blocks) * T + t) * C + 4 * q;
+        x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 16);
+    }
+    // register prefetch of a block's inputs for this lane's row: saved dilated-conv output, dropout mask
+    f32x4 pf_u0, pf_u1, pf_d0, pf_d1;
     auto prefetch = [&](int blk) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
-        pf_x0 = pf_x1 = pf_u0 = pf_u1 = z;
+        pf_u0 = pf_u1 = z;
         pf_d0 = pf_d1 = one;
         if (live) {
-            const float *xp = acts + (((size_t)(n0 + p) * nslot + blk) * T + t) * C + 4 * q;
-            pf_x0 = *reinterpret_cast<const f32x4 *>(xp), pf_x1 = *reinterpret_cast<const f32x4 *>(xp + 16);
             const float *up = upre + (((size_t)(n0 + p) * a.n_blocks + blk) * T + t) * C + 4 * q;
             pf_u0 = *reinterpret_cast<const f32x4 *>(up), pf_u1 = *reinterpret_cast<const f32x4 *>(up + 16);
             if (drop) {
@@ -283,23 +321,46 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     };
     auto ld16 = [&](const char *ptr) { return *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(ptr, 16)); };
 
+    // this wave's weight-gradient item (phase B), if any, and the accumulators it hands from one block to the next: an item's 18 atomic
+    // instructions are SENT at the top of the next block, while the tile waves run phase A -- the CU's texture path takes about a
+    // lane's word per cycle for them (4 176 words = 2 us per block), and sent inside phase B that time stood between two barriers
+    const int my_kind = wave < 16 ? (int)(((G == 2 ? kItemOfWave2 : kItemOfWave1) >> (4 * wave)) & 15ull) : 15;
+    f32x4 acc[2][2], accb[2];
+    int pend_blk = -1;  // the block whose gradients acc / accb hold
+    auto flush = [&]() {
+        if (pend_blk < 0 || (a.split3 & 1)) return;  // (the mask: timing probe)
+        const size_t wo = a.off.blk0 + (size_t)pend_blk * a.off.blk_stride;
+        const bool w2 = my_kind == 0;
+        const int tap = w2 ? 1 : my_kind - 1;
+        const unsigned gbase = (unsigned)(w2 ? wo + 3 * C * C + C : wo + (size_t)tap * C * C);
+        const unsigned gbias = (unsigned)(w2 ? wo + 3 * C * C + C + C * C : wo + 3 * C * C);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    gadd(grad, a.gq, gbase + (unsigned)((16 * mt + 4 * q + r) * C + 16 * n2 + j), acc[mt][n2][r]);
+        if (tap == 1 && q == 0) {
+            gadd(grad, a.gq, gbias + j, accb[0][0]);
+            gadd(grad, a.gq, gbias + 16 + j, accb[1][0]);
+        }
+        pend_blk = -1;
+    };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // images zeroed, the last block's operands in the slot
     lap(0);
 
     for (int blk = a.n_blocks - 1; blk >= 0; --blk) {
         const int d = 1 << (blk % a.n_dil);
-        const size_t wo = a.off.blk0 + (size_t)blk * a.off.blk_stride;
-        const size_t o_k1 = wo, o_b1 = wo + 3 * C * C, o_k2 = o_b1 + C, o_b2 = o_k2 + C * C;
         if (blk < a.n_blocks - 1) stage_w1(blk);  // (phase C of the block before is behind the barrier)
+        flush();  // the previous block's weight gradients (the waves that own an item own no tile at W = 68: phase A is their idle time)
         // ---- phase A ---------------------------------------------------------------------------------------------------------------
         if (has_tile && !(a.split3 & 4)) {  // (wave-uniform; the mask: timing probes)
             const f32x4 u0 = pf_u0, u1 = pf_u1, dm0 = pf_d0, dm1 = pf_d1;
             bf16x8 sel[2];
             make_sel(sel);
             bf16x8 vh, vl;
-            split8(pf_x0, pf_x1, vh, vl);
-            transpose_store(sel, vh, vl, img + GH::o_x, img + GH::o_x + GH::h_x, GH::sxt, GH::halo + 16 * u);
             float r0[4], r1[4], mx = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -315,14 +376,24 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
                 y1[r] = live ? r1[r] * inv_m * dm1[r] : 0.f;
             }
             split8(y0, y1, vh, vl);
+            {   // this block's input from its output: the forward's own 1x1 products on the same y
+                const float *b2 = reinterpret_cast<const float *>(wslot + kBiasPiece * 1024);
+                f32x4 o0 = *reinterpret_cast<const f32x4 *>(b2 + 4 * q), o1 = *reinterpret_cast<const f32x4 *>(b2 + 16 + 4 * q);
+                o0 = product3(ld16(wslot + (8 * 64 + lane) * 16), ld16(wslot + kSlotLo + (8 * 64 + lane) * 16), vh, vl, o0);
+                o1 = product3(ld16(wslot + (9 * 64 + lane) * 16), ld16(wslot + kSlotLo + (9 * 64 + lane) * 16), vh, vl, o1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x0[r] = live ? x0[r] - o0[r] : 0.f, x1[r] = live ? x1[r] - o1[r] : 0.f;
+            }
             transpose_store(sel, vh, vl, img + GH::o_y, img + GH::o_y + GH::h_t, GH::st, 16 * u);
+            split8(x0, x1, vh, vl);
+            transpose_store(sel, vh, vl, img + GH::o_x, img + GH::o_x + GH::h_x, GH::sxt, GH::halo + 16 * u);
             bf16x8 gh, gl;
             split8(g0, g1, gh, gl);
             transpose_store(sel, gh, gl, img + GH::o_g, img + GH::o_g + GH::h_t, GH::st, 16 * u);
             // dyn[c][frame] = sum_co W2[c][co] g[frame][co]
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-            d0 = product3(ld16(wslot + (0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (0 * 64 + lane) * 16), gh, gl, d0);
-            d1 = product3(ld16(wslot + (1 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (1 * 64 + lane) * 16), gh, gl, d1);
+            d0 = product3(ld16(wslot + (0 * 64 + lane) * 16), ld16(wslot + kSlotLo + (0 * 64 + lane) * 16), gh, gl, d0);
+            d1 = product3(ld16(wslot + (1 * 64 + lane) * 16), ld16(wslot + kSlotLo + (1 * 64 + lane) * 16), gh, gl, d1);
             float s1 = 0.f, cnt = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -359,13 +430,13 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         // item = dW2 | dW1 tap 0, 1, 2 over all the workgroup's patches: the whole 32 x 32 gradient as 2 x 2 accumulator tiles, so that a k step's eight
         // operand reads feed twelve products (as sixteen 16 x 16 jobs of four reads per three products the phase sat on LDS bandwidth:
         // 384 KB per block and CU)
-        for (int slot = wave; slot < 16; slot += nw) {
-            const int kind = (int)(((G == 2 ? kItemOfWave2 : kItemOfWave1) >> (4 * slot)) & 15ull);
-            if (kind == 15 || (a.split3 & 2)) continue;
+        do {
+            const int kind = my_kind;
+            if (kind == 15 || (a.split3 & 2)) break;
             const bool w2 = kind == 0;
             const int tap = w2 ? 1 : kind - 1;
             const int off = w2 ? 0 : (tap - 1) * d;
-            if (off != 0 && d >= T) continue;  // a side tap that only ever sees the zero padding
+            if (off != 0 && d >= T) break;  // a side tap that only ever sees the zero padding
             const bool bias = tap == 1;        // dW2: db2 = column sums of g; centre tap: db1 = column sums of du
             const int oA = w2 ? GH::o_y : GH::o_x, hA = w2 ? GH::h_t : GH::h_x, sA = w2 ? GH::st : GH::sxt;
             const int oB = w2 ? GH::o_g : GH::o_du_t;
@@ -374,7 +445,6 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             const int aoff = arow + 2 * (eA & ~1), boff = oB + j * GH::st + 16 * q;
             const unsigned sh = (eA & 1) ? 16u : 0u;
             const bool aligned = (off & 7) == 0;
-            f32x4 acc[2][2], accb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x8 ones;
@@ -431,20 +501,8 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             };
             if (aligned) run(std::true_type{});
             else run(std::false_type{});
-            const unsigned gbase = (unsigned)(w2 ? o_k2 : o_k1 + (size_t)tap * C * C), gbias = (unsigned)(w2 ? o_b2 : o_b1);
-            if (a.split3 & 1) continue;  // (timing probe)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        gadd(grad, a.gq, gbase + (unsigned)((16 * mt + 4 * q + r) * C + 16 * n2 + j), acc[mt][n2][r]);
-            if (bias && q == 0) {
-                gadd(grad, a.gq, gbias + j, accb[0][0]);
-                gadd(grad, a.gq, gbias + 16 + j, accb[1][0]);
-            }
-        }
+            pend_blk = blk;
+        } while (false);
         // (behind phase B: its 24 registers would be live across the items' 2 x 2 accumulators and operands; the waves that own whole
         // tiles have no item and get here straight from the barrier)
         if (blk > 0) prefetch(blk - 1);
@@ -459,8 +517,8 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
                 const int row = ok ? t - off : T;  // row T of the du images stays zero
                 const bf16x8 bh = ld16(img + GH::o_du + row * kDuRow + 16 * q), bl = ld16(img + GH::o_du + geo.h_du + row * kDuRow + 16 * q);
                 const int e0 = 2 + 2 * tap;
-                g0 = product3(ld16(wslot + (e0 * 64 + lane) * 16), ld16(wslot + kSlotHalf + (e0 * 64 + lane) * 16), bh, bl, g0);
-                g1 = product3(ld16(wslot + ((e0 + 1) * 64 + lane) * 16), ld16(wslot + kSlotHalf + ((e0 + 1) * 64 + lane) * 16), bh, bl, g1);
+                g0 = product3(ld16(wslot + (e0 * 64 + lane) * 16), ld16(wslot + kSlotLo + (e0 * 64 + lane) * 16), bh, bl, g0);
+                g1 = product3(ld16(wslot + ((e0 + 1) * 64 + lane) * 16), ld16(wslot + kSlotLo + ((e0 + 1) * 64 + lane) * 16), bh, bl, g1);
             }
             if (!live) g0 = g1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -474,6 +532,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         lap(5);
     }
 
+    flush();
     // ---- initial Conv1D(32, 1): dW0[f][c] = sum_t x[t][f] g[t][c], db0[c] = sum_t g[t][c] -- exact-f32 products (k = 4 steps over the
     // frames, X read from global memory as in tcn_backward_mfma_kernel); g goes to LDS as f32 rows of stride SX over the patch's images ----
     const int RPm = 16 * geo.units;
@@ -554,13 +613,18 @@ bool bwd_geo(int T, int n_dil, BwdGeo *g) {
     g->per_patch = g->o_du + 2 * g->h_du;
     g->per_patch = (g->per_patch + 15) / 16 * 16;
     if ((size_t)16 * g->units * SX * sizeof(float) > (size_t)g->per_patch) return false;  // the tail's f32 rows live on the patch's images
-    g->G = (size_t)2 * g->per_patch + 2 * kSlotHalf <= kLdsMax ? 2 : 1;
-    return (size_t)g->G * g->per_patch + 2 * kSlotHalf <= kLdsMax;
+    g->G = (size_t)2 * g->per_patch + kSlotBytes <= kLdsMax ? 2 : 1;
+    return (size_t)g->G * g->per_patch + kSlotBytes <= kLdsMax;
 }
 
 }  // namespace
 
 namespace smh_tcn {
+
+bool backward_bf16_supported(int T, int n_dil) {
+    BwdGeo geo;
+    return bwd_geo(T, n_dil, &geo) && ((geo.G == 2 && geo.K32 <= 3) || (geo.G == 1 && geo.K32 == 4));
+}
 
 int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, const float *d_x, const float *d_flat,
                          const float *d_acts, const float *d_drop_tcn, const float *d_dpre, float *d_grad, const float *d_upre,
@@ -570,10 +634,10 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
     BwdArgs bp = ba;
     bp.split3 = 0;  // this kernel's timing-probe mask (results invalid): 1 no atomics, 2 no phase B, 4 no phase A, 8 no phase C
     if (const char *ev = smh::probe_env("SMH_BWD_PROBE")) bp.split3 = atoi(ev);
-    SMH_REQUIRE(ba.NH <= kPS, "launch_backward_bf16: %d Dense-on-trunk outputs exceed the %d of a dpre row", ba.NH, kPS);
+    SMH_REQUIRE(ba.NH <= kPS && ba.n_classes <= 8 && ba.n_heads <= kMaxHeads, "launch_backward_bf16: %d Dense-on-trunk outputs", ba.NH);
     // workspace: [the blocks' kernels as split A operands | gt (N, T, 32)]
-    const size_t pack_bytes = ((size_t)ba.n_blocks * 2 * kUnitsPerBlk * 64 * 16 + 255) / 256 * 256;
-    const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float);
+    const size_t pack_bytes = (size_t)ba.n_blocks * kSlotBytes;
+    const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float) + ((bp.split3 & 16) ? (size_t)8 * 4 * (1u << 20) : 0);
     if (*pack_cap < need) {
         if (*d_pack) SMH_CHECK_HIP(hipFree(*d_pack));
         *d_pack = nullptr, *pack_cap = 0;
@@ -582,7 +646,7 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
     }
     float *d_gt = reinterpret_cast<float *>(static_cast<char *>(*d_pack) + pack_bytes);
     if (ba.n_blocks > 0) {
-        const int n = ba.n_blocks * kUnitsPerBlk * 64;
+        const int n = ba.n_blocks * (kUnitsPerBlk + 1) * 64;
         hipLaunchKernelGGL(pack_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_flat, ba.off, ba.n_blocks, (bf16x8 *)*d_pack);
         int rc = smh::launch_status("pack_bwd_kernel");
         if (rc) return rc;
@@ -593,7 +657,7 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
         int rc = smh::launch_status("dtrunk_kernel");
         if (rc) return rc;
     }
-    const size_t lds = (size_t)geo.G * geo.per_patch + 2 * kSlotHalf;
+    const size_t lds = (size_t)geo.G * geo.per_patch + kSlotBytes;
     auto go = [&](auto kern) -> int {
         SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((ba.N + geo.G - 1) / geo.G), dim3(512 * geo.G), lds, st, bp, geo, d_x, d_flat, (const bf16x8 *)*d_pack,
