@@ -15,17 +15,27 @@
 // products over FRAMES (dW[c][co] = sum_t a[t][c] b[t][co]), whose operands must hold eight consecutive frames per lane: they read
 // those images.
 //
-// One workgroup = G patches (2 at the reference's W = 68: 2 x 65 KB of images + one 16 KB operand slot), 8 waves per patch; per block
-//   A  (tile waves) x, y = norm(relu(u)), g, du -> frame-contiguous images xT, yT, gT, duT (hi and lo) and du rows (hi, lo);
-//      dyn = W2 . g (6 products) and the relu / channel-max backward in registers;
+// One workgroup = G patches (2 at the reference's W = 68: 2 x 65 KB of images + one 21 KB operand slot), 8 waves per patch.  What a
+// lane keeps in registers over the whole kernel, for its row of its 16-frame tile: g (d loss / d block output -- it starts as
+// dtrunk_kernel's product) and x (the residual stream, walked backwards: x_b = x_b+1 - W2 . y_b - b2, so the forward saves the TCN
+// output alone and neither side moves the 111 MB of block inputs).  Per block:
+//   A  (tile waves) y = norm(relu(u)) from the saved conv output u, x_b (6 products), dyn = W2 . g (6 products), the relu /
+//      channel-max backward in registers -> du; frame-contiguous images xT, yT, gT, duT (hi and lo) and du rows (hi, lo);
+//      the next block's u is requested from HBM as soon as this one's is dead;
 //   -- barrier --
-//   B  (all waves) the 16 weight-gradient tiles dW2 (2 x 2), dW1[tap] (3 x 2 x 2), one per wave over the workgroup's patches, K =
-//      frames (three steps of 32 at W = 68); a side tap reads xT at frame t + off: whole 8-frame chunks when the dilation is a multiple
-//      of 8 (a chunk outside the patch is zero, no halo needed), otherwise five dwords and a funnel shift inside an 8-frame halo.  The bias gradients are two more products with an all-ones A operand.
-//   C  (tile waves) g += sum_tap W1[tap] . du[t - off] (18 products), g stays in the lane's registers over the whole kernel;
+//   B  (four waves that own no tile at W = 68) one weight-gradient item each -- dW2, dW1 tap 0 / 1 / 2 -- as 2 x 2 accumulator tiles
+//      over the frames of all the workgroup's patches (K = three steps of 32 frames per patch at W = 68; eight operand reads per
+//      twelve products).  A side tap reads xT at frame t + off: whole 8-frame chunks when the dilation is a multiple of 8 (a chunk
+//      outside the patch is zero), otherwise five dwords and a funnel shift inside an 8-frame halo.  Bias gradients: two more
+//      products per step with an all-ones A operand.  The item's 18 atomic instructions go out at the top of the NEXT block, under
+//      the tile waves' phase A (the CU's texture path takes ~a word per cycle for them: 2 us per block);
+//   C  (tile waves, beside B) g += sum_tap W1[tap] . du[t - off] (18 products);
 //   -- barrier --
-// The block's kernels come as split A operands from a packed copy (pack_bwd_kernel, once per step) by LDS-DMA into ONE slot: the
-// 1x1 kernel (used in A) is replaced behind the first barrier, the dilated kernel (used in C) behind the second.
+// The block's kernels come as split A operands from a packed copy (pack_bwd_kernel, once per step) by LDS-DMA into ONE slot: what
+// phase A reads (both orientations of the 1x1 kernel, its bias) is replaced behind the first barrier, the dilated kernel (phase C)
+// behind the second.  No barrier is a __syncthreads(): its fence is an s_waitcnt vmcnt(0), which on a wave with atomics or an HBM
+// prefetch in flight is a wait for their round trips; the waves that request DMA pieces count their waits instead.
+// Measured (510 patches, W = 68, one MI355X): 169 us + 8 us dtrunk_kernel + 3 us pack, against 280 us for the exact-f32 kernel.
 #include <algorithm>
 #include <cstdlib>
 
@@ -209,7 +219,6 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int q = lane >> 4, j = lane & 15;
     const int n0 = blockIdx.x * G;
-    if (a.split3 & 16) grad = const_cast<float *>(gt) + (size_t)a.N * T * C + (size_t)(blockIdx.x & 7) * (1u << 20);  // (timing probe)
     const int g_here = min(G, a.N - n0);
     // this wave's patch and 16-frame tile (patch 1's tiles sit one wave further on, so that the 5 + 5 tiles of two 68-frame patches
     // spread 3 / 3 / 2 / 2 over the four SIMDs)
@@ -225,7 +234,6 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     const bool stamping = STAMPS && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 5);
     if (stamping) tlast = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long t_entry = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     auto lap = [&](int i) {
         if constexpr (!STAMPS) return;
         if (stamping) {
@@ -421,8 +429,20 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             }
             transpose_store(sel, vh, vl, img + GH::o_du_t, img + GH::o_du_t + GH::h_t, GH::st, 16 * u);
         }
+        // the next block's saved conv outputs and masks, requested as soon as this block's are dead: they come from HBM, and requested
+        // behind the barrier they had only phase C to arrive in (the tile waves then stood at the top of the next phase A)
+        if (blk > 0) prefetch(blk - 1);
         lap(1);
-        if (didx >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the dilated kernel have landed
+        // this wave's pieces of the dilated kernel have landed: everything but the two / four loads of the prefetch just issued (loads
+        // return in order; a wave without a tile issued none)
+        if (didx >= 0) {
+            if (has_tile && blk > 0) {
+                if (drop) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads(): see the barrier at the end of the block)
         lap(2);
         if (blk > 0) stage_w2(blk - 1);  // phase A was the 1x1 kernel's last reader
@@ -503,9 +523,6 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
             else run(std::false_type{});
             pend_blk = blk;
         } while (false);
-        // (behind phase B: its 24 registers would be live across the items' 2 x 2 accumulators and operands; the waves that own whole
-        // tiles have no item and get here straight from the barrier)
-        if (blk > 0) prefetch(blk - 1);
         lap(3);
         // ---- phase C: g[frame][c] += sum_tap sum_co W1[tap][c][co] du[frame - off][co] ------------------------------------------
         if (has_tile && !(a.split3 & 8)) {
@@ -584,11 +601,6 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         }
     }
     lap(6);
-    if (STAMPS && tid == 0 && (blockIdx.x % 32 == 0 || blockIdx.x == gridDim.x - 1)) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        printf("tcn_backward_bf16_kernel wg %d xcc %u: entry %llu exit %llu (x10 ns)\n", (int)blockIdx.x, xcc & 15u, t_entry, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
     if (stamping)
         printf("tcn_backward_bf16_kernel wg0 wave %d (x10 ns, summed over %d blocks): prologue %llu  A %llu  barrier1 %llu  B %llu  C %llu  barrier2 %llu  layer0 %llu\n",
                wave, a.n_blocks, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
@@ -637,7 +649,7 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
     SMH_REQUIRE(ba.NH <= kPS && ba.n_classes <= 8 && ba.n_heads <= kMaxHeads, "launch_backward_bf16: %d Dense-on-trunk outputs", ba.NH);
     // workspace: [the blocks' kernels as split A operands | gt (N, T, 32)]
     const size_t pack_bytes = (size_t)ba.n_blocks * kSlotBytes;
-    const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float) + ((bp.split3 & 16) ? (size_t)8 * 4 * (1u << 20) : 0);
+    const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float);
     if (*pack_cap < need) {
         if (*d_pack) SMH_CHECK_HIP(hipFree(*d_pack));
         *d_pack = nullptr, *pack_cap = 0;

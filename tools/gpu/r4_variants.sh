@@ -30,3 +30,4 @@ tr dwh_valu SMH_DWH_VALU=1
 tr heads_global SMH_HEADS_GLOBAL=1
 tr skew2 SMH_TCN_SKEW=2
 tr deterministic SMH_DETERMINISTIC=1
+tr bwd_f32 SMH_BWD_BF16=0
