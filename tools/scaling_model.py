@@ -15,7 +15,7 @@ between an optimistic (alpha 1.5 us per ring step, beta = 7 links x 153 GB/s x 0
 the all-reduce is exposed (it sits on the main stream between the backward pass and the optimiser; only the NEXT batch's front
 end overlaps it).
 
-    python tools/scaling_model.py [--steps 200] > profiles/r04_scaling_model.json
+    python tools/scaling_model.py [--steps 200] [--dtype bf16] > profiles/r04_scaling_model.json
 """
 import argparse
 import json
@@ -62,13 +62,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="the training legs' matrix pipe (tools/bench_train.py --dtype)")
     args = ap.parse_args()
     py = sys.executable
     sw = ["--steps", str(args.steps), "--warmup", str(args.warmup)]
     inf = run_json([py, "bench.py", "--no-cpu-baseline", "--steady-steps", "0", *sw])
     train = {}
     for b in (510, 255, 126, 63):
-        j = run_json([py, "tools/bench_train.py", "--batch", str(b), "--serial", *sw])
+        j = run_json([py, "tools/bench_train.py", "--batch", str(b), "--serial", "--dtype", args.dtype, *sw])
         train[b] = {"ms_per_step": j["ms_per_step"], "clips_per_step": j.get("config", {}).get("clips_per_gpu_per_step", b)}
     ar = run_json([py, "-c", ALLREDUCE])
 
@@ -97,6 +98,7 @@ def main():
     print(json.dumps({
         "what": "MODEL, NOT A MEASUREMENT: 1/2/4/8-GPU throughput predicted from one-GPU step times + the one-rank RCCL all-reduce floor "
                 "+ an assumed xGMI term (see tools/scaling_model.py)",
+        "training_dtype": args.dtype,
         "measured_on_one_gpu": {"inference_ms_per_1024_clips": inf["ms_per_step"], "inference_clips_per_s": inf["value"],
                                 "training_step_ms_by_local_batch": train, "rccl_allreduce_one_rank": ar},
         "assumptions": {"t_link_us": "2 (G-1) alpha + 2 (G-1)/G * bytes / beta", "corners_alpha_us_beta_GBs": corners,
