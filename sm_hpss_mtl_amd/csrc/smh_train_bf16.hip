@@ -431,6 +431,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         }
         // the next block's saved conv outputs and masks, requested as soon as this block's are dead: they come from HBM, and requested
         // behind the barrier they had only phase C to arrive in (the tile waves then stood at the top of the next phase A)
+        asm volatile("" ::: "memory");  // (the counted wait below relies on these loads being issued BEHIND the DMA requests of this block)
         if (blk > 0) prefetch(blk - 1);
         lap(1);
         // this wave's pieces of the dilated kernel have landed: everything but the two / four loads of the prefetch just issued (loads

@@ -392,6 +392,32 @@ def test_deterministic_gradients_are_bit_reproducible(ncls, N):
     assert torch.equal(whole, det[0])
 
 
+@pytest.mark.parametrize("N", [510, 7])
+def test_deterministic_gradients_with_the_bf16_step(N):
+    """The split-bf16 backward sends its weight gradients through the same accumulation as the f32 kernel (gadd): with
+    `deterministic_gradients` its 255 workgroups' contributions meet in fixed-point integer atomics, and three runs give
+    `torch.equal` buckets; against the float-atomic gradient of the same step the values agree to summation noise."""
+    if os.environ.get("SMH_DETERMINISTIC"):
+        pytest.skip("the mode under test is forced on by SMH_DETERMINISTIC: nothing to compare it with")
+    from sm_hpss_mtl_amd.model import B3MTL
+    w, x, y, drop_tcn, drop_heads = _problem(3, N, seed=21)
+    m = B3MTL(n_feat=240, patch_size=68, n_classes=3)
+    m.set_weights_dict(w)
+    m.train_dtype = "bf16"
+    dt, dh = torch.from_numpy(drop_tcn).cuda(), torch.from_numpy(drop_heads).cuda()
+
+    def grad():
+        m.train_on_batch(x, y, drop_tcn=dt, drop_heads=dh, apply=False)
+        torch.cuda.synchronize()
+        return m._bucket_tensor().clone()
+    free = grad()
+    m.deterministic_gradients = True
+    det = [grad() for _ in range(3)]
+    assert torch.equal(det[0], det[1]) and torch.equal(det[0], det[2])
+    n = m.count_params()
+    assert float((det[0][:n] - free[:n]).abs().max()) <= 2e-6 * float(free[:n].abs().max())
+
+
 def test_growing_the_trainer_keeps_the_optimiser_state():
     """A batch larger than the trainer's capacity re-creates the native trainer: momentum must survive.  Step at N = 48, then
     at N = 96 (capacity 64 -> 96) against a model whose trainer had room for 96 from the start."""
