@@ -126,9 +126,8 @@ struct GeoK {
 constexpr unsigned long long kItemOfWave2 = 0xFFFFFFF3120FFFFFull;  // waves 5..8: dW2, tap 1, tap 0, tap 2
 constexpr unsigned long long kItemOfWave1 = 0xFFFFFFFF3120FFFFull;  // one patch per workgroup (8 waves): waves 4..7
 
-// canonical f32 kernels -> split A operands, one thread per 16-byte unit: dst[blk][hi 512 | lo 512] with unit e = mt (W2: dyn[c] = sum_co
-// k2[c][co] g[co]) or 2 + 2 tap + mt (W1: dx[c] += sum_co k1[tap][c][co] du[t - off][co]); lane (i, kg) holds row c = 16 mt + i, columns
-// co in the accumulator's channel order k' = 8 kg + e'
+// canonical f32 kernels -> the slot's image (above), one thread per 16-byte unit of the hi half: lane (i, kg) of an operand unit holds row
+// 16 mt + i of its matrix and the eight columns k' = 8 kg + e' in the accumulator's channel order; the lo half is written beside it
 __global__ void pack_bwd_kernel(const float *__restrict__ flat, Offsets off, int n_blocks, bf16x8 *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_blocks * (kUnitsPerBlk + 1) * 64) return;
@@ -243,7 +242,7 @@ tcn_backward_bf16_kernel(BwdArgs a, BwdGeo geo, const float *__restrict__ X, con
         }
     };
     for (int i = tid; i < G * geo.per_patch / 16; i += nt) reinterpret_cast<u32x4s *>(smb)[i] = u32x4s{0u, 0u, 0u, 0u};
-    // the block's operands: 16 pieces of 1 KiB (64 lanes x 16 bytes): hi W2 (0, 1), hi W1 (2..7), lo W2 (8, 9), lo W1 (10..15)
+    // the block's operands, piece by piece (kSlotPieces of 1 KiB = 64 lanes x 16 bytes, layout above) from the packed copy into the slot
     auto stage_piece = [&](int blk, int piece) {
         const char *src = reinterpret_cast<const char *>(pk + ((size_t)blk * kSlotPieces + piece) * 64 + lane);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
