@@ -315,7 +315,9 @@ def test_gradients_and_losses_at_the_config4_batch(ncls, N, schedule, monkeypatc
         assert np.abs(bn[hi * 32 + 16:hi * 32 + 32] - var).max() <= 1e-4 * max(1.0, np.abs(var).max())
 
 
-@pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68), (3, 3, 99), (3, 510, 68), (3, 4, 20), (3, 3, 128)])
+@pytest.mark.parametrize("ncls,N,W", [(3, 6, 68), (5, 5, 68), (3, 1, 68), (3, 3, 99), (3, 510, 68), (3, 4, 20), (3, 3, 128),
+                                      # the edges of the LDS plan: 1 / 2 / 3 / 4 steps of 32 frames, 96 = the longest patch with two per workgroup
+                                      (3, 3, 15), (3, 3, 32), (3, 3, 33), (3, 3, 64), (3, 3, 65), (3, 5, 96), (3, 3, 97)])
 def test_bf16_backward_equals_the_f32_backward_on_the_same_forward(ncls, N, W, monkeypatch):
     """dtype bf16 runs the residual blocks' backward on the bf16 matrix pipe with split operands (smh_train_bf16.hip); SMH_BWD_BF16=0
     keeps the exact-f32 kernel behind the same bf16 forward.  Both read the gates that forward saved, so the two gradients are the
