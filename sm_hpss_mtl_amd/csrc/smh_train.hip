@@ -607,7 +607,7 @@ template <bool WLDS, int MAXT>
 __global__ void __launch_bounds__(kMThreads, WLDS ? 4 : 1)
 tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__restrict__ flatw,
                          const float *__restrict__ acts, const float *__restrict__ drop, const float *__restrict__ dpre,
-                         float *__restrict__ grad, int RPm, const float *__restrict__ upre) {
+                         float *__restrict__ grad, int RPm, const float *__restrict__ upre, const float *__restrict__ gt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int T = a.T, nslot = a.n_blocks + 1;
     const int n0 = blockIdx.x * kMG;
@@ -632,7 +632,15 @@ tcn_backward_mfma_kernel(BwdArgs a, const float *__restrict__ X, const float *__
     if (tid < kZW) ZW[tid] = 0.f;
     __syncthreads();
     // ---- Dense-on-trunk backward: G = relu'(x) * (dpre @ Wh^T) ------------------------------------------------
-    for (int i = tid; i < rows * C; i += nt) {
+    // gt: the product as dtrunk_kernel computed it for the whole batch (smh_train_bf16.hip) -- here every workgroup read the whole
+    // 444 KB Dense kernel from L2 for its one patch; nullptr (SMH_DTRUNK=0): the loop below
+    if (gt) {
+        for (int i = tid; i < rows * (C / 4); i += nt) {
+            const int R = i >> 3, c4 = (i & 7) * 4;
+            *reinterpret_cast<f32x4 *>(G + (size_t)R * SX + c4) = *reinterpret_cast<const f32x4 *>(gt + ((size_t)n0 * T + R) * C + c4);
+        }
+    }
+    for (int i = tid; i < (gt ? 0 : rows * C); i += nt) {
         const int R = i / C, c = i - R * C;
         const int g = R / T, t = R - g * T;
         const size_t k = (size_t)t * C + c;
@@ -1243,6 +1251,7 @@ struct smh_trainer {
     unsigned long long *d_gq = nullptr;       // deterministic mode: fixed-point gradient accumulators (n_params), else nullptr
     float *d_sumsq = nullptr, *d_scratch_out = nullptr;
     float *d_upre = nullptr;  // (max_batch, n_blocks, T, 32): TrainIO::upre
+    float *d_gt = nullptr;       // (max_batch, T, 32): d loss / d (TCN output), dtrunk_kernel's product for the f32 backward
     void *d_bwd_pack = nullptr;  // the blocks' kernels as split bf16 A operands of the backward pass (smh_train_bf16.hip), dtype 1 only
     size_t bwd_pack_cap = 0;
     double *d_l2part = nullptr;   // l2_penalty_kernel: kL2Chunks partial sums per head, then its arrival ticket
@@ -1328,6 +1337,7 @@ extern "C" void smh_trainer_destroy(smh_trainer *t) {
     (void)hipFree(t->d_l2part);
     (void)hipFree(t->d_gq);
     (void)hipFree(t->d_bwd_pack);
+    (void)hipFree(t->d_gt);
     delete t;
 }
 
@@ -1424,17 +1434,24 @@ extern "C" int smh_train_step_f32(smh_trainer *t, const float *d_x, const float 
     }
     if (bwd_done || ((short_ok || long_ok) && !getenv("SMH_TRAIN_VALU"))) {
         const dim3 grid((N + kMG - 1) / kMG);
+        float *d_gt = nullptr;
+        if (!bwd_done && !(getenv("SMH_DTRUNK") && atoi(getenv("SMH_DTRUNK")) == 0)) {  // (SMH_DTRUNK=0: the in-kernel loop, A/B and tests)
+            if (!t->d_gt) SMH_CHECK_HIP(hipMalloc((void **)&t->d_gt, (size_t)t->max_batch * ba.D * sizeof(float)));
+            d_gt = t->d_gt;
+            rc = launch_dtrunk(ba, m->d_flat, t->d_acts, t->d_dpre, d_gt, st);
+            if (rc) return rc;
+        }
         if (bwd_done) {
         } else if (short_ok) {
             auto kern = tcn_backward_mfma_kernel<true, kMfmaMaxT>;
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
             hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_m, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre, t->d_grad,
-                               RPm, (const float *)t->d_upre);
+                               RPm, (const float *)t->d_upre, (const float *)d_gt);
         } else {
             auto kern = tcn_backward_mfma_kernel<false, kMfmaLongT>;
             SMH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long));
             hipLaunchKernelGGL(kern, grid, dim3(kMThreads), lds_long, st, ba, d_x, m->d_flat, t->d_acts, d_drop_tcn, t->d_dpre,
-                               t->d_grad, RPm, (const float *)t->d_upre);
+                               t->d_grad, RPm, (const float *)t->d_upre, (const float *)d_gt);
         }
         rc = smh::launch_status("tcn_backward_mfma_kernel");
         if (rc) return rc;

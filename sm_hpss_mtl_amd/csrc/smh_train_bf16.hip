@@ -638,6 +638,13 @@ bool backward_bf16_supported(int T, int n_dil) {
     return bwd_geo(T, n_dil, &geo) && ((geo.G == 2 && geo.K32 <= 3) || (geo.G == 1 && geo.K32 == 4));
 }
 
+int launch_dtrunk(const BwdArgs &ba, const float *d_flat, const float *d_acts, const float *d_dpre, float *d_gt, hipStream_t st) {
+    SMH_REQUIRE(ba.NH <= kPS && ba.n_classes <= 8 && ba.n_heads <= kMaxHeads, "launch_dtrunk: %d Dense-on-trunk outputs", ba.NH);
+    const int tiles = (ba.N + 15) / 16;
+    hipLaunchKernelGGL(dtrunk_kernel, dim3(ba.T * C / 16, std::max(1, std::min(8, tiles / 16))), dim3(256), 0, st, ba, d_flat, d_acts, d_dpre, d_gt);
+    return smh::launch_status("dtrunk_kernel");
+}
+
 int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, const float *d_x, const float *d_flat,
                          const float *d_acts, const float *d_drop_tcn, const float *d_dpre, float *d_grad, const float *d_upre,
                          hipStream_t st) {
@@ -646,7 +653,6 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
     BwdArgs bp = ba;
     bp.split3 = 0;  // this kernel's timing-probe mask (results invalid): 1 no atomics, 2 no phase B, 4 no phase A, 8 no phase C
     if (const char *ev = smh::probe_env("SMH_BWD_PROBE")) bp.split3 = atoi(ev);
-    SMH_REQUIRE(ba.NH <= kPS && ba.n_classes <= 8 && ba.n_heads <= kMaxHeads, "launch_backward_bf16: %d Dense-on-trunk outputs", ba.NH);
     // workspace: [the blocks' kernels as split A operands | gt (N, T, 32)]
     const size_t pack_bytes = (size_t)ba.n_blocks * kSlotBytes;
     const size_t need = pack_bytes + (size_t)ba.N * ba.T * C * sizeof(float);
@@ -664,9 +670,7 @@ int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, con
         if (rc) return rc;
     }
     {
-        const int tiles = (ba.N + 15) / 16;
-        hipLaunchKernelGGL(dtrunk_kernel, dim3(ba.T * C / 16, std::max(1, std::min(8, tiles / 16))), dim3(256), 0, st, ba, d_flat, d_acts, d_dpre, d_gt);
-        int rc = smh::launch_status("dtrunk_kernel");
+        int rc = launch_dtrunk(ba, d_flat, d_acts, d_dpre, d_gt, st);
         if (rc) return rc;
     }
     const size_t lds = (size_t)geo.G * geo.per_patch + kSlotBytes;

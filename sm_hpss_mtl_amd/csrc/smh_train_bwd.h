@@ -32,6 +32,8 @@ struct BwdArgs {
 // dtype 1.  *d_pack / *pack_cap: the trainer-owned buffer of the blocks' kernels as split A operands (grown on demand, rebuilt every
 // call: the weights move every step).  Returns SMH_OK, an error, or kBwdBf16Unsupported when the patch geometry does not fit its LDS
 // plan (the caller then runs the f32 kernel).
+// d loss / d (TCN output before its final relu), (N, T, 32), as its own small product (dtrunk_kernel): both backward kernels start from it
+int launch_dtrunk(const BwdArgs &ba, const float *d_flat, const float *d_acts, const float *d_dpre, float *d_gt, hipStream_t st);
 constexpr int kBwdBf16Unsupported = -1000;
 int launch_backward_bf16(const BwdArgs &ba, void **d_pack, size_t *pack_cap, const float *d_x, const float *d_flat,
                          const float *d_acts, const float *d_drop_tcn, const float *d_dpre, float *d_grad, const float *d_upre,

@@ -31,3 +31,4 @@ tr heads_global SMH_HEADS_GLOBAL=1
 tr skew2 SMH_TCN_SKEW=2
 tr deterministic SMH_DETERMINISTIC=1
 tr bwd_f32 SMH_BWD_BF16=0
+tr dtrunk_in_kernel SMH_DTRUNK=0

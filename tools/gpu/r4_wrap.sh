@@ -18,6 +18,7 @@ tr heads_global SMH_HEADS_GLOBAL=1
 tr skew2 SMH_TCN_SKEW=2
 tr deterministic SMH_DETERMINISTIC=1
 tr bwd_f32 SMH_BWD_BF16=0
+tr dtrunk_in_kernel SMH_DTRUNK=0
 python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/r4/scaling_model_bf16.json"))
