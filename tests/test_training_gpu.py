@@ -162,14 +162,17 @@ def test_evaluate_on_the_device_equals_the_host_arithmetic(ncls, monkeypatch):
     np.testing.assert_allclose(dev_a, host_a, rtol=1e-9, atol=1e-12)
 
 
-def test_end_to_end_synthetic_training_batches():
-    """Config-4 shaped path: synthetic audio -> HIP front end -> patches + reference labels -> fit."""
+@pytest.mark.parametrize("train_dtype", ["f32", "bf16"])
+def test_end_to_end_synthetic_training_batches(train_dtype):
+    """Config-4 shaped path: synthetic audio -> HIP front end -> patches + reference labels -> fit; with train_dtype "bf16" (config 5's
+    "mixed bf16 CNN") forward and backward of the residual blocks run on the bf16 matrix pipe, weights and optimiser stay f32."""
     from sm_hpss_mtl_amd.batching import synthetic_batch
     from sm_hpss_mtl_amd.frontend import Frontend, FrontendConfig
     from sm_hpss_mtl_amd.lib.proposed_architectures import get_Lemaire_MTL_model
     fe = Frontend(FrontendConfig())
     rng = np.random.default_rng(0)
     model, _ = get_Lemaire_MTL_model(TR_STEPS=6, N_MELS=240, n_classes=3, patch_size=68, seed=2)
+    model.train_dtype = train_dtype
 
     def gen():
         while True:
