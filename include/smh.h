@@ -423,9 +423,11 @@ int smh_trainer_reset_state(smh_trainer *t, void *stream);
  * pass over the gradient and 8-byte atomics (tools/bench_train.py --deterministic states the step time). */
 int smh_trainer_set_deterministic(smh_trainer *t, int on, void *stream);
 /* Arithmetic of the training step's matrix products (BASELINE config 5: "mixed bf16 CNN").  dtype 0 (default): exact-f32 MFMA.
- * dtype 1: the training FORWARD runs on the bf16 matrix pipe with split operands -- every f32 operand as hi + lo bf16, three bf16
- * products per f32 product, f32 accumulators; master weights, saved activations, losses, the backward pass and the optimiser stay
- * f32 (the forward's outputs are within 1e-4 of the f32 forward's, gradients within the same 2e-3 of the oracle). */
+ * dtype 1: the residual blocks' FORWARD and BACKWARD run on the bf16 matrix pipe with split operands -- every f32 operand as hi + lo
+ * bf16, three bf16 products per f32 product, f32 accumulators; master weights, gates, losses, heads, the Dense gradients and the
+ * optimiser stay f32.  The forward's outputs are within 1e-4 of the f32 forward's; the backward agrees with the f32 backward on the same
+ * forward to 2e-4 (relative L2 per tensor); against the float64 oracle the gradients sit where the forward's 1e-5 puts the relu /
+ * channel-maximum gates (2-3e-2 of a tensor's norm).  Patches longer than 128 frames keep the f32 backward. */
 int smh_trainer_set_dtype(smh_trainer *t, int dtype);
 /* General optimiser step.  optimizer 0 = SGD (beta1 = momentum; what smh_trainer_apply_sgd_f32 calls), 1 = Adam,
  * 2 = Nadam as tf.keras 2.x implements it (momentum schedule u_t = beta1 (1 - 0.5 * 0.96^(0.004 t)); the optimiser of the
